@@ -1,0 +1,180 @@
+/*
+ * nerfx -- C ABI of the MI355X (gfx950) NeRF render/train hot path.
+ *
+ * The reference (yliess86/NeRF) has no FFI: its boundary is the Python API of
+ * `nerf.core`.  Each entry point below names the reference function(s) whose
+ * arithmetic it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - Every pointer is a BORROWED device pointer to contiguous row-major fp32
+ *    (int64 where stated) unless marked "host".  The library never frees or
+ *    keeps caller memory; outputs and workspaces are caller-allocated.
+ *  - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and
+ *    the call returns without synchronising.
+ *  - Return value: 0 on success, a negative NERFX_E_* code on failure;
+ *    `nerfx_last_error()` then returns a thread-local message.
+ *  - Functions are re-entrant.  A `nerfx_model_t` caches packed weight copies;
+ *    it may be used concurrently for rendering but `nerfx_model_refresh` must
+ *    not overlap (on another stream) with kernels that read the same handle.
+ */
+#ifndef NERFX_H
+#define NERFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERFX_VERSION 100            /* 0.1.0 */
+
+#define NERFX_E_ARG      (-1)        /* bad argument / unsupported shape      */
+#define NERFX_E_HIP      (-2)        /* a HIP runtime call failed             */
+#define NERFX_E_NOMEM    (-3)        /* allocation failed (model create only) */
+
+/* encoder kinds */
+#define NERFX_ENC_POSITIONAL 0       /* features.py:22-36  */
+#define NERFX_ENC_FOURIER    1       /* features.py:40-52  */
+/* hidden activations (model.py:28; train.py:235) */
+#define NERFX_ACT_RELU       0
+#define NERFX_ACT_LEAKY_RELU 1       /* negative slope 0.01 (torch default)   */
+#define NERFX_ACT_SILU       2
+/* arithmetic of the MLP contractions */
+#define NERFX_PREC_FP32      0       /* v_mfma_f32_32x32x2_f32, exact fp32    */
+#define NERFX_PREC_BF16      1       /* v_mfma_f32_32x32x16_bf16, fp32 accum  */
+
+typedef struct nerfx_model nerfx_model_t;
+
+/* Shape of one radiance field -- the constructor arguments of
+ * `NeRF(phi_x, phi_d, width, depth, activ, resid)` (model.py:22-55). */
+typedef struct {
+    int32_t enc_x_kind;  /* NERFX_ENC_*                                        */
+    int32_t enc_x_n;     /* N_freqs (positional) or features F (fourier)        */
+    int32_t enc_d_kind;
+    int32_t enc_d_n;
+    int32_t width;       /* 16..256, multiple of 16                             */
+    int32_t depth;       /* even, >= 2: depth/2 layers in each trunk half       */
+    int32_t activ;       /* NERFX_ACT_*                                         */
+    int32_t resid;       /* 0/1: concatenate phi_x in front of fc_2's input     */
+} nerfx_model_desc_t;
+
+typedef struct {
+    int32_t compute_units;
+    int32_t wavefront;
+    int32_t lds_bytes_per_cu;
+    int32_t clock_khz;
+    int64_t hbm_bytes;
+    char    arch[32];
+} nerfx_device_info_t;
+
+/* ---- library ------------------------------------------------------------ */
+int         nerfx_version(void);
+const char* nerfx_last_error(void);
+int         nerfx_device_info(int device, nerfx_device_info_t* out /* host */);
+
+/* ---- model handle -------------------------------------------------------
+ * `tensors` (host array of device pointers) lists, in this order:
+ *   enc_x table, enc_d table        (freq_bands (N,) or b (F,3); features.py:102,138)
+ *   fc_1.i.0.weight, fc_1.i.0.bias  for i in 0..depth/2-1          (model.py:46)
+ *   fc_2.i.0.weight, fc_2.i.0.bias  for i in 0..depth/2-1          (model.py:47)
+ *   sigma.0.weight, sigma.0.bias    (model.py:49)
+ *   features.weight, features.bias  (model.py:51)
+ *   rgb.0.weight, rgb.0.bias, rgb.2.weight, rgb.2.bias              (model.py:52-55)
+ * i.e. 2 + 2*depth + 8 pointers; weights are torch Linear layout (out, in).
+ * create() allocates the packed copies and packs once; refresh() re-packs from
+ * the same pointers (call it after every optimizer step). */
+int  nerfx_model_create(const nerfx_model_desc_t* desc /* host */,
+                        const float* const* tensors /* host array */, int n_tensors,
+                        void* stream, nerfx_model_t** out /* host */);
+int  nerfx_model_refresh(nerfx_model_t* model, const float* const* tensors, int n_tensors,
+                         void* stream);
+void nerfx_model_destroy(nerfx_model_t* model);
+
+/* ---- K1: stratified sampling + encoding (standalone form) ----------------
+ * Replaces uniform_bounded_z_values + segment_lengths + uniform_bounded_rays
+ * (ray.py:91-99, :60-66, :129-135) and the encoders (features.py:32-36, :50-52).
+ * `u` (B, n) = the uniforms `rand_like(t)` would draw, or NULL for perturb off.
+ * Outputs (any may be NULL): t, delta (B, n); rx (B, n, 3);
+ * phi_x (B, n, Ex); phi_d (B, Ed) -- the direction encoding is per ray. */
+int nerfx_sample_encode_fwd(const float* ro, const float* rd, int64_t n_rays,
+                            float tn, float tf, int n_samples, const float* u,
+                            int enc_x_kind, int enc_x_n, const float* enc_x_table,
+                            int enc_d_kind, int enc_d_n, const float* enc_d_table,
+                            float* t, float* delta, float* rx, float* phi_x, float* phi_d,
+                            void* stream);
+
+/* Encode arbitrary points: phi (n_points, E) = encoder(v (n_points, 3)).
+ * Replaces PositionalEncoding.forward / FourierFeatures.forward
+ * (features.py:104-113, :140-149). */
+int nerfx_encode_fwd(const float* v, int64_t n_points, int kind, int n, const float* table,
+                     float* phi, void* stream);
+
+/* ---- K2: the radiance-field MLP ------------------------------------------
+ * Replaces NeRF.forward (model.py:68-78) including both encoders, both output
+ * activations (activations.py:18-20, :33-35) and the two concatenations.
+ * Point form: x (M, 3), d (M, 3) -> sigma (M), rgb (M, 3).
+ * rgb == NULL computes the density only (what renderer.py:134 consumes). */
+int nerfx_mlp_fwd_points(const nerfx_model_t* model, int precision,
+                         const float* x, const float* d, int64_t n_points,
+                         float* sigma, float* rgb, void* stream);
+
+/* Ray form: sample m = ray * n_samples + i sits at ro + rd * t[m] and looks
+ * along rd (ray.py:132-133, :226-227), so positions never touch memory. */
+int nerfx_mlp_fwd_rays(const nerfx_model_t* model, int precision,
+                       const float* ro, const float* rd, const float* t,
+                       int64_t n_rays, int n_samples,
+                       float* sigma, float* rgb, void* stream);
+
+/* ---- K3: alpha compositing ------------------------------------------------
+ * Replaces segment_lengths (ray.py:60-66), raymarch_volume + exclusive_cumprod
+ * (renderer.py:23-26, :50-57) and the depth reduction (renderer.py:203).
+ * `delta` may be NULL: it is then formed from t and rd.  rgb / rgb_map /
+ * depth_map may be NULL (weights only). */
+int nerfx_composite_fwd(const float* sigma, const float* rgb, const float* t, const float* rd,
+                        const float* delta, int64_t n_rays, int n_samples,
+                        float* weights, float* rgb_map, float* depth_map, void* stream);
+
+/* segment_lengths alone (ray.py:50-66): delta (B,n) from t (B,n) and rd (B,3). */
+int nerfx_segment_lengths(const float* t, const float* rd, int64_t n_rays, int n_samples,
+                          float* delta, void* stream);
+
+/* Backward of the above w.r.t. sigma and rgb (autograd of renderer.py:50-57,
+ * :203).  g_rgb_map (B,3), g_depth (B) and g_weights (B,n) may each be NULL
+ * (= zero).  Outputs g_sigma (B,n), g_rgb (B,n,3). */
+int nerfx_composite_bwd(const float* sigma, const float* rgb, const float* t, const float* rd,
+                        const float* delta, int64_t n_rays, int n_samples,
+                        const float* g_rgb_map, const float* g_depth, const float* g_weights,
+                        float* g_sigma, float* g_rgb, void* stream);
+
+/* ---- K4: hierarchical sampling ---------------------------------------------
+ * Replaces pdf_z_values (ray.py:158-188) and the concatenate + sort of pdf_rays
+ * (ray.py:220-223).  t_c, w_c (B, nc) from the coarse pass; `u` (B, nf) or NULL
+ * for linspace(0, 1, nf).  Outputs: t_sorted (B, nc+nf) required; cdf (B, nc-1),
+ * idx int64 (B, nf) and t_pdf (B, nf) optional (NULL to skip). */
+int nerfx_pdf_sample(const float* t_c, const float* w_c, int64_t n_rays, int nc, int nf,
+                     const float* u, float* t_sorted, float* cdf, int64_t* idx, float* t_pdf,
+                     void* stream);
+
+/* torch.searchsorted(cdf, u, right=True) (ray.py:174) on caller-supplied rows:
+ * cdf (B, n_cdf) ascending, u (B, n_u) -> idx int64 (B, n_u).  Bit-exact. */
+int nerfx_searchsorted_right(const float* cdf, const float* u, int64_t n_rows, int n_cdf,
+                             int n_u, int64_t* idx, void* stream);
+
+/* ---- fused render -----------------------------------------------------------
+ * Replaces BoundedVolumeRaymarcher.render_volume for train=False
+ * (renderer.py:198-205): coarse pass (density only) -> K4 -> fine pass ->
+ * composite.  nf == 0 renders the coarse pass with colour.  `u_c` (B,nc) /
+ * `u_f` (B,nf) are optional uniforms (perturb=True).  `workspace` must hold
+ * nerfx_render_workspace_bytes(n_rays, nc, nf) bytes.  Outputs: t, weights
+ * (B, nc+nf), depth_map (B), rgb_map (B,3). */
+int64_t nerfx_render_workspace_bytes(int64_t n_rays, int nc, int nf);
+int nerfx_render_fwd(const nerfx_model_t* coarse, const nerfx_model_t* fine, int precision,
+                     const float* ro, const float* rd, int64_t n_rays,
+                     float tn, float tf, int nc, int nf, const float* u_c, const float* u_f,
+                     void* workspace, int64_t workspace_bytes,
+                     float* t, float* weights, float* depth_map, float* rgb_map, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFX_H */

@@ -1,0 +1,47 @@
+"""Volume renderer (reference nerf/core/renderer.py): the drop-in boundary.
+
+`BoundedVolumeRaymarcher.render_volume` keeps the reference's signature and
+return tuple and drives the HIP kernels: stratified sampling, the fused MLP for
+the coarse pass (density only), inverse-CDF resampling + merge, the fused MLP on
+all Nc + Nf samples, and the wavefront-scan compositor."""
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .. import ops
+
+
+class BoundedVolumeRaymarcher:
+    """BoundedVolumeRaymarcher(tn, tf, samples_c=64, samples_f=64)
+    (reference renderer.py:147-171)."""
+
+    def __init__(self, tn: float, tf: float, samples_c: int = 64, samples_f: int = 64) -> None:
+        assert tf > tn, "[NeRF] `tf` should always be > `tn`"
+        assert samples_c > 0, "[NeRF] `samples_c` should always be > 0"
+        self.tn, self.tf = tn, tf
+        self.samples_c, self.samples_f = samples_c, samples_f
+        self.samples = samples_c + samples_f
+
+    def render_volume(self, coarse, fine, ro: Tensor, rd: Tensor, perturb: Optional[bool] = False,
+                      train: Optional[bool] = False) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+        """-> t (B,N), weights (B,N), depth_map (B,), rgb_map (B,3)
+        (reference renderer.py:173-205).
+
+        `perturb` draws the stratification / inverse-CDF uniforms from torch's
+        generator of the rays' device, coarse first, as the reference does.
+        With `train`, gradients reach the parameters of `fine` through the fine
+        pass only (the coarse pass and the sample positions carry none), and the
+        requires_grad flags of both modules are toggled exactly as in
+        reference renderer.py:133,137."""
+        B, nc, nf = ro.size(0), self.samples_c, self.samples_f
+        u_c = torch.rand((B, nc), device=ro.device) if perturb else None
+        u_f = torch.rand((B, nf), device=ro.device) if (perturb and nf > 0) else None
+        if train:
+            if nf > 0:
+                coarse.requires_grad(False)
+            return ops.render_train(coarse, fine if nf > 0 else coarse, ro, rd, self.tn, self.tf, nc, nf, u_c, u_f)
+        with torch.no_grad():
+            hc = ops.handle_for(coarse)
+            hf = ops.handle_for(fine) if nf > 0 else None
+            return ops.render(hc, hf, ro, rd, self.tn, self.tf, nc, nf, u_c, u_f)

@@ -1,0 +1,186 @@
+// Model handle: plans the unit stream of a radiance field and packs the caller's
+// fp32 torch-layout weights into it on the device (no host round trip, so a
+// refresh after every optimizer step is one short kernel sequence on the stream).
+#include "mlp.hpp"
+
+#include <new>
+
+namespace nerfx {
+
+int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
+    NERFX_REQUIRE(d.width >= 16 && d.width <= 256 && d.width % 16 == 0,
+                  "width %d unsupported (16..256, multiple of 16)", d.width);
+    NERFX_REQUIRE(d.depth >= 2 && d.depth % 2 == 0 && d.depth <= 16, "depth %d unsupported (even, 2..16)", d.depth);
+    NERFX_REQUIRE(d.activ >= NERFX_ACT_RELU && d.activ <= NERFX_ACT_SILU, "unknown activation %d", d.activ);
+    for (int s = 0; s < 2; ++s) {
+        const int kind = s ? d.enc_d_kind : d.enc_x_kind, n = s ? d.enc_d_n : d.enc_x_n;
+        NERFX_REQUIRE(kind == NERFX_ENC_POSITIONAL || kind == NERFX_ENC_FOURIER, "unknown encoder kind %d", kind);
+        NERFX_REQUIRE(n >= 1 && (kind == NERFX_ENC_POSITIONAL ? n : 3 * n) <= MAX_TABLE, "encoder size %d unsupported", n);
+    }
+    p.desc = d;
+    p.prec = prec;
+    auto pow2_tiles = [](int dim) { int t = 1; while (32 * t < dim) t *= 2; return t; };
+    p.wt = pow2_tiles(d.width);          // tiles are padded to a power of two so that a
+    p.rt = pow2_tiles(d.width / 2);      // k-block of n_tiles units never straddles a ring chunk
+    p.hd = d.depth / 2;
+    p.n_layers = 2 * p.hd + 3;
+    const int ex_cols = enc_width(d.enc_x_kind, d.enc_x_n), ed_cols = enc_width(d.enc_d_kind, d.enc_d_n);
+    const int ex_units = enc_units(d.enc_x_kind, d.enc_x_n, prec), ed_units = enc_units(d.enc_d_kind, d.enc_d_n, prec);
+    int64_t unit = 0;
+    auto pad = [](int64_t u) { return (u + CHUNK_UNITS - 1) / CHUNK_UNITS * CHUNK_UNITS; };
+    for (int li = 0; li < p.n_layers; ++li) {
+        LayerPlan& L = p.layer[li];
+        L = LayerPlan{};
+        L.n_tiles = p.wt; L.out_dim = d.width; L.chain_tiles = p.wt; L.chain_dim = d.width;
+        const bool with_x = li == 0 || (li == p.hd && d.resid);
+        if (with_x) { L.enc_units = ex_units; L.enc_kind = d.enc_x_kind; L.enc_n = d.enc_x_n; L.enc_cols = ex_cols; }
+        if (li == 0) { L.chain_tiles = 0; L.chain_dim = 0; }
+        if (li == 2 * p.hd) unit = pad(unit);                       // features starts a chunk
+        if (li == 2 * p.hd + 1) {                                   // rgb.0
+            L.n_tiles = p.rt; L.out_dim = d.width / 2;
+            L.enc_units = ed_units; L.enc_kind = d.enc_d_kind; L.enc_n = d.enc_d_n; L.enc_cols = ed_cols;
+        }
+        if (li == 2 * p.hd + 2) {                                   // rgb.2
+            L.n_tiles = 1; L.out_dim = 3; L.chain_tiles = p.rt; L.chain_dim = d.width / 2;
+        }
+        L.in_dim = L.enc_cols + L.chain_dim;
+        L.unit0 = unit;
+        unit += units_of(L, prec);
+        if (li == 2 * p.hd - 1) p.trunk_units = pad(unit);
+    }
+    p.total_units = pad(unit);
+    p.sigw_off = p.n_layers * BIAS_STRIDE;
+    p.sigb_off = p.sigw_off + BIAS_STRIDE;
+    p.tabx_off = p.sigb_off + 4;
+    p.tabd_off = p.tabx_off + MAX_TABLE;
+    p.const_floats = p.tabd_off + MAX_TABLE;
+    return 0;
+}
+
+// One thread per packed 16-byte lane slice of one layer.
+template <int PREC>
+__global__ __launch_bounds__(256) void pack_layer_kernel(const float* __restrict__ W, LayerPlan L,
+                                                         void* __restrict__ stream) {
+    constexpr int EPL = PREC == NERFX_PREC_BF16 ? 8 : 4;          // elements per lane per unit
+    const int k_units = L.enc_units + L.chain_tiles * units_per_tile(PREC);
+    const int64_t n_slices = (int64_t)k_units * L.n_tiles * 64;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < n_slices; s += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(s & 63);
+        const int64_t unit = s >> 6;                               // = (grp * k_units + ku) * ng + t
+        const int ng = group_tiles(PREC, L.n_tiles);
+        const int t = (int)(unit % ng), gk = (int)(unit / ng);
+        const int grp = gk / k_units, ku = gk - grp * k_units, nt = grp * ng + t;
+        const int row = 32 * nt + (lane & 31), h = lane >> 5;
+        float v[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            int col;
+            if (ku < L.enc_units) {
+                col = enc_slot_col(L.enc_kind, L.enc_n, enc_unit_slot(PREC, ku, h, e));
+            } else {
+                const int f = chain_unit_feature(PREC, ku - L.enc_units, h, e);
+                col = f < L.chain_dim ? L.enc_cols + f : -1;
+            }
+            v[e] = (row < L.out_dim && col >= 0) ? W[(int64_t)row * L.in_dim + col] : 0.0f;
+        }
+        char* dst = (char*)stream + (L.unit0 + unit) * UNIT_BYTES + lane * 16;
+        if (PREC == NERFX_PREC_BF16) {
+            __bf16 b[8];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) b[e] = (__bf16)v[e];
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(b);
+        } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[EPL > 3 ? 3 : 0]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_vector_kernel(const float* __restrict__ src, int n, int cap,
+                                                          float* __restrict__ dst) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cap; i += gridDim.x * 256) dst[i] = i < n ? src[i] : 0.0f;
+}
+
+static int tensor_index(const ModelPlan& p, int li, bool bias) {
+    const int hd = p.hd;
+    int base;
+    if (li < 2 * hd) base = 2 + 2 * li;                             // fc_1.*, fc_2.*
+    else if (li == 2 * hd) base = 2 + 4 * hd + 2;                   // features (after sigma)
+    else if (li == 2 * hd + 1) base = 2 + 4 * hd + 4;               // rgb.0
+    else base = 2 + 4 * hd + 6;                                     // rgb.2
+    return base + (bias ? 1 : 0);
+}
+
+static int pack_all(nerfx_model* m, const float* const* tensors, hipStream_t stream) {
+    const ModelPlan& p0 = m->plan[0];
+    const nerfx_model_desc_t& d = p0.desc;
+    for (int i = 0; i < m->n_tensors; ++i) NERFX_REQUIRE(tensors[i] != nullptr, "tensor %d is NULL", i);
+    for (int prec = 0; prec < 2; ++prec) {
+        const ModelPlan& p = m->plan[prec];
+        NERFX_HIP(hipMemsetAsync(m->stream_dev[prec], 0, (size_t)p.total_units * UNIT_BYTES, stream));
+        for (int li = 0; li < p.n_layers; ++li) {
+            const LayerPlan& L = p.layer[li];
+            const int64_t slices = (int64_t)units_of(L, prec) * 64;
+            const int grid = (int)std::min<int64_t>((slices + 255) / 256, 4096);
+            const float* W = tensors[tensor_index(p, li, false)];
+            if (prec == NERFX_PREC_BF16)
+                hipLaunchKernelGGL(pack_layer_kernel<NERFX_PREC_BF16>, dim3(grid), dim3(256), 0, stream, W, L, m->stream_dev[prec]);
+            else
+                hipLaunchKernelGGL(pack_layer_kernel<NERFX_PREC_FP32>, dim3(grid), dim3(256), 0, stream, W, L, m->stream_dev[prec]);
+        }
+    }
+    auto vec = [&](const float* src, int n, int cap, int off) {
+        hipLaunchKernelGGL(pack_vector_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, src, n, cap, m->const_dev + off);
+    };
+    for (int li = 0; li < p0.n_layers; ++li)
+        vec(tensors[tensor_index(p0, li, true)], p0.layer[li].out_dim, BIAS_STRIDE, li * BIAS_STRIDE);
+    vec(tensors[2 + 4 * p0.hd], d.width, BIAS_STRIDE, p0.sigw_off);
+    vec(tensors[2 + 4 * p0.hd + 1], 1, 4, p0.sigb_off);
+    vec(tensors[0], d.enc_x_kind == NERFX_ENC_POSITIONAL ? d.enc_x_n : 3 * d.enc_x_n, MAX_TABLE, p0.tabx_off);
+    vec(tensors[1], d.enc_d_kind == NERFX_ENC_POSITIONAL ? d.enc_d_n : 3 * d.enc_d_n, MAX_TABLE, p0.tabd_off);
+    return launch_status("pack kernels");
+}
+
+}  // namespace nerfx
+
+using namespace nerfx;
+
+extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* const* tensors, int n_tensors,
+                                  void* stream, nerfx_model_t** out) {
+    NERFX_REQUIRE(desc && tensors && out, "NULL argument");
+    *out = nullptr;
+    nerfx_model* m = new (std::nothrow) nerfx_model{};
+    if (!m) return fail(NERFX_E_NOMEM, "out of host memory");
+    for (int prec = 0; prec < 2; ++prec)
+        if (int e = make_plan(*desc, prec, m->plan[prec])) { delete m; return e; }
+    m->n_tensors = 2 + 2 * desc->depth + 8;
+    if (n_tensors != m->n_tensors) {
+        const int want = m->n_tensors;
+        delete m;
+        return fail(NERFX_E_ARG, "expected %d tensors for depth %d, got %d", want, desc->depth, n_tensors);
+    }
+    hipError_t e = hipGetDevice(&m->device);
+    for (int prec = 0; prec < 2 && e == hipSuccess; ++prec)
+        e = hipMalloc(&m->stream_dev[prec], (size_t)m->plan[prec].total_units * UNIT_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->const_dev, (size_t)m->plan[0].const_floats * sizeof(float));
+    if (e != hipSuccess) {
+        nerfx_model_destroy(m);
+        return fail(e == hipErrorOutOfMemory ? NERFX_E_NOMEM : NERFX_E_HIP, "model allocation failed: %s", hipGetErrorString(e));
+    }
+    if (int rc = pack_all(m, tensors, (hipStream_t)stream)) { nerfx_model_destroy(m); return rc; }
+    *out = m;
+    return 0;
+}
+
+extern "C" int nerfx_model_refresh(nerfx_model_t* m, const float* const* tensors, int n_tensors, void* stream) {
+    NERFX_REQUIRE(m && tensors, "NULL argument");
+    NERFX_REQUIRE(n_tensors == m->n_tensors, "expected %d tensors, got %d", m->n_tensors, n_tensors);
+    return pack_all(m, tensors, (hipStream_t)stream);
+}
+
+extern "C" void nerfx_model_destroy(nerfx_model_t* m) {
+    if (!m) return;
+    for (int prec = 0; prec < 2; ++prec)
+        if (m->stream_dev[prec]) (void)hipFree(m->stream_dev[prec]);
+    if (m->const_dev) (void)hipFree(m->const_dev);
+    delete m;
+}

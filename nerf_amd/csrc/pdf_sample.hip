@@ -1,0 +1,172 @@
+// K4: hierarchical (inverse-CDF) sampling + merge with the coarse samples.
+//
+// One 64-lane wavefront owns one ray: interior coarse weights -> pdf -> cdf by a
+// wave scan, `searchsorted(right=True)` by binary search in LDS, the lerp of
+// ray.py:182-186, then the nc + nf values are put in ascending order (rank
+// merge when the fine samples are already ascending, bitonic sort otherwise).
+#include "common.hpp"
+
+namespace nerfx {
+
+constexpr int K4_MAX = 256;                       // max nc and max nf
+constexpr int K4_SORT = 512;                      // pow2 >= nc + nf
+
+// cumsum in double, rounded to fp32 per element: what torch's CPU cumsum does.
+__device__ __forceinline__ double wave_incl_sum(double v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// #{k in [0, n) : a[k] <= x}  ==  torch.searchsorted(a, x, right=True)
+__device__ __forceinline__ int upper_bound(const float* a, int n, float x) {
+    int lo = 0, len = n;
+    while (len > 0) {
+        const int half = len >> 1;
+        const bool go = a[lo + half] <= x;
+        lo = go ? lo + half + 1 : lo;
+        len = go ? len - half - 1 : half;
+    }
+    return lo;
+}
+// #{k in [0, n) : a[k] < x}
+__device__ __forceinline__ int lower_bound(const float* a, int n, float x) {
+    int lo = 0, len = n;
+    while (len > 0) {
+        const int half = len >> 1;
+        const bool go = a[lo + half] < x;
+        lo = go ? lo + half + 1 : lo;
+        len = go ? len - half - 1 : half;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(64) void pdf_sample_kernel(
+    const float* __restrict__ t_c, const float* __restrict__ w_c, int64_t n_rays, int nc, int nf,
+    const float* __restrict__ u_g, float* __restrict__ t_sorted, float* __restrict__ cdf_out,
+    int64_t* __restrict__ idx_out, float* __restrict__ t_pdf_out) {
+    __shared__ float tc[K4_MAX], cdf[K4_MAX], bins[K4_MAX], tp[K4_MAX], srt[K4_SORT];
+    __shared__ int unsorted;
+    const int lane = threadIdx.x;
+    const int nb = nc - 1;                         // bins (mid points) and cdf entries
+    const int nw = nc - 2;                         // interior weights
+    for (int64_t ray = blockIdx.x; ray < n_rays; ray += gridDim.x) {
+        // -- pdf and cdf (ray.py:161-164, :220) --------------------------------
+        float part = 0.f;
+        for (int i = lane; i < nc; i += 64) {
+            const float t = t_c[ray * nc + i];
+            tc[i] = t;
+            if (i >= 1 && i <= nw) part += __fadd_rn(w_c[ray * nc + i], 1e-5f);
+        }
+        if (lane == 0) unsorted = 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        const float total = part;
+        __syncthreads();
+        double carry = 0.0;
+        for (int k0 = 0; k0 < nw; k0 += 64) {      // cdf[k + 1] = sum_{j <= k} pdf_j
+            const int k = k0 + lane;
+            const float pdf = k < nw ? __fadd_rn(w_c[ray * nc + k + 1], 1e-5f) / total : 0.f;
+            const double inc = wave_incl_sum((double)pdf, lane) + carry;
+            if (k < nw) cdf[k + 1] = (float)inc;
+            carry = __shfl(inc, 63, 64);
+        }
+        if (lane == 0) cdf[0] = 0.f;
+        for (int i = lane; i < nb; i += 64) bins[i] = __fmul_rn(0.5f, __fadd_rn(tc[i], tc[i + 1]));
+        __syncthreads();
+        if (cdf_out)
+            for (int i = lane; i < nb; i += 64) cdf_out[ray * nb + i] = cdf[i];
+        // -- inverse cdf (ray.py:166-186) ---------------------------------------
+        for (int j = lane; j < nf; j += 64) {
+            const float u = u_g ? u_g[ray * nf + j] : linspace_at(0.f, 1.f, nf, j);
+            const int idx = upper_bound(cdf, nb, u);
+            const int below = max(idx - 1, 0), above = min(idx, nw);
+            const float cb = cdf[below], ca = cdf[above], bb = bins[below], ba = bins[above];
+            float den = __fsub_rn(ca, cb);
+            den = den < 1e-5f ? 1.0f : den;
+            const float frac = __fsub_rn(u, cb) / den;
+            const float t = __fadd_rn(bb, __fmul_rn(frac, __fsub_rn(ba, bb)));
+            tp[j] = t;
+            if (idx_out) idx_out[ray * nf + j] = idx;
+            if (t_pdf_out) t_pdf_out[ray * nf + j] = t;
+        }
+        __syncthreads();
+        // -- merge (ray.py:223) ---------------------------------------------------
+        for (int j = lane; j + 1 < nf; j += 64)
+            if (!(tp[j] <= tp[j + 1])) unsorted = 1;                   // benign race: all write 1
+        for (int i = lane; i + 1 < nc; i += 64)
+            if (!(tc[i] <= tc[i + 1])) unsorted = 1;
+        __syncthreads();
+        const int n = nc + nf;
+        float* out = t_sorted + ray * n;
+        if (!unsorted) {
+            // both runs ascending: final slot = own index + rank in the other run
+            for (int i = lane; i < nc; i += 64) out[i + lower_bound(tp, nf, tc[i])] = tc[i];
+            for (int j = lane; j < nf; j += 64) out[j + upper_bound(tc, nc, tp[j])] = tp[j];
+        } else {
+            int p2 = 1;
+            while (p2 < n) p2 <<= 1;
+            for (int i = lane; i < p2; i += 64) {
+                float v = i < nc ? tc[i] : (i < n ? tp[i - nc] : INFINITY);
+                srt[i] = v == v ? v : INFINITY;                          // NaNs sort last
+            }
+            __syncthreads();
+            for (int k = 2; k <= p2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = lane; i < p2; i += 64) {
+                        const int partner = i ^ j;
+                        if (partner > i) {
+                            const float a = srt[i], b = srt[partner];
+                            const bool up = (i & k) == 0;
+                            if ((a > b) == up) { srt[i] = b; srt[partner] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = lane; i < n; i += 64) out[i] = srt[i];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void searchsorted_right_kernel(
+    const float* __restrict__ cdf, const float* __restrict__ u, int64_t n_rows, int n_cdf, int n_u,
+    int64_t* __restrict__ idx) {
+    const int64_t total = n_rows * n_u;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t row = q / n_u;
+        idx[q] = upper_bound(cdf + row * n_cdf, n_cdf, u[q]);
+    }
+}
+
+}  // namespace nerfx
+
+using namespace nerfx;
+
+extern "C" int nerfx_pdf_sample(const float* t_c, const float* w_c, int64_t n_rays, int nc, int nf,
+                                const float* u, float* t_sorted, float* cdf, int64_t* idx, float* t_pdf,
+                                void* stream) {
+    NERFX_REQUIRE(n_rays >= 0, "n_rays < 0");
+    NERFX_REQUIRE(nc >= 3 && nc <= K4_MAX, "nc %d out of range [3, %d]", nc, K4_MAX);
+    NERFX_REQUIRE(nf >= 1 && nf <= K4_MAX, "nf %d out of range [1, %d]", nf, K4_MAX);
+    if (n_rays == 0) return 0;
+    NERFX_REQUIRE(t_c && w_c && t_sorted, "t_c / w_c / t_sorted is NULL");
+    const int grid = (int)std::min<int64_t>(n_rays, 256 * 32);
+    hipLaunchKernelGGL(pdf_sample_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, t_c, w_c, n_rays,
+                       nc, nf, u, t_sorted, cdf, idx, t_pdf);
+    return launch_status("pdf_sample_kernel");
+}
+
+extern "C" int nerfx_searchsorted_right(const float* cdf, const float* u, int64_t n_rows, int n_cdf,
+                                        int n_u, int64_t* idx, void* stream) {
+    NERFX_REQUIRE(n_rows >= 0 && n_cdf >= 1 && n_u >= 1, "bad sizes");
+    if (n_rows == 0) return 0;
+    NERFX_REQUIRE(cdf && u && idx, "cdf / u / idx is NULL");
+    const int grid = (int)std::min<int64_t>((n_rows * n_u + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(searchsorted_right_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, cdf, u,
+                       n_rows, n_cdf, n_u, idx);
+    return launch_status("searchsorted_right_kernel");
+}

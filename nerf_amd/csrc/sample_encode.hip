@@ -1,0 +1,148 @@
+// K1 (standalone form): stratified sampling along rays + sin/cos encodings.
+//
+// One workgroup walks one ray at a time.  Encodings are produced pair-wise
+// (one sincos per angle) into an LDS tile laid out exactly like the output rows,
+// then streamed to HBM with full-width coalesced stores: the kernel is bound by
+// the 4*(n*Ex) bytes per ray it writes, not by the transcendental math.
+#include "common.hpp"
+
+namespace nerfx {
+
+constexpr int K1_THREADS = 256;
+constexpr int K1_TILE_FLOATS = 8192;   // 32 KiB LDS tile
+
+// Encode `count` points whose coordinates sit in LDS (px/py/pz) into `out`
+// (count x E, row-major, global).  All threads of the workgroup take part.
+__device__ void encode_tile(int kind, int n, const float* __restrict__ table,
+                            const float* px, const float* py, const float* pz, int count,
+                            float* tile, float* __restrict__ out) {
+    const int E = enc_width(kind, n), P = enc_pairs(kind, n);
+    const int rows_per_pass = K1_TILE_FLOATS / E;
+    for (int r0 = 0; r0 < count; r0 += rows_per_pass) {
+        const int rows = min(rows_per_pass, count - r0);
+        for (int q = threadIdx.x; q < rows * P; q += K1_THREADS) {
+            const int r = q / P, p = q - r * P;
+            float s, c;
+            sincosf(enc_angle(kind, table, p, px[r0 + r], py[r0 + r], pz[r0 + r]), &s, &c);
+            tile[r * E + enc_pair_col(kind, n, p, 0)] = s;
+            tile[r * E + enc_pair_col(kind, n, p, 1)] = c;
+        }
+        if (kind == NERFX_ENC_POSITIONAL)
+            for (int q = threadIdx.x; q < rows * 3; q += K1_THREADS) {
+                const int r = q / 3, c = q - 3 * r;
+                tile[r * E + c] = c == 0 ? px[r0 + r] : (c == 1 ? py[r0 + r] : pz[r0 + r]);
+            }
+        __syncthreads();
+        float* dst = out + (size_t)r0 * E;
+        for (int q = threadIdx.x; q < rows * E; q += K1_THREADS) dst[q] = tile[q];
+        __syncthreads();
+    }
+}
+
+constexpr int K1_MAX_SAMPLES = 1024;
+
+__global__ __launch_bounds__(K1_THREADS) void sample_encode_kernel(
+    const float* __restrict__ ro, const float* __restrict__ rd, int64_t n_rays, float tn, float tf,
+    int n, const float* __restrict__ u, int kx, int nx, const float* __restrict__ tx, int kd, int nd,
+    const float* __restrict__ td, float* __restrict__ t_out, float* __restrict__ delta_out,
+    float* __restrict__ rx_out, float* __restrict__ phi_x, float* __restrict__ phi_d) {
+    __shared__ float tile[K1_TILE_FLOATS];
+    __shared__ float ts[K1_MAX_SAMPLES], px[K1_MAX_SAMPLES], py[K1_MAX_SAMPLES], pz[K1_MAX_SAMPLES];
+    const int Ex = enc_width(kx, nx), Ed = enc_width(kd, nd);
+    for (int64_t ray = blockIdx.x; ray < n_rays; ray += gridDim.x) {
+        const float ox = ro[3 * ray], oy = ro[3 * ray + 1], oz = ro[3 * ray + 2];
+        const float dx = rd[3 * ray], dy = rd[3 * ray + 1], dz = rd[3 * ray + 2];
+        for (int i = threadIdx.x; i < n; i += K1_THREADS) {
+            const float t = u ? stratified_at(tn, tf, n, i, u[ray * n + i]) : linspace_at(tn, tf, n, i);
+            ts[i] = t;
+            px[i] = __fadd_rn(ox, __fmul_rn(dx, t));           // ray.py:132, two roundings
+            py[i] = __fadd_rn(oy, __fmul_rn(dy, t));
+            pz[i] = __fadd_rn(oz, __fmul_rn(dz, t));
+        }
+        __syncthreads();
+        const float len = norm3(dx, dy, dz);
+        for (int i = threadIdx.x; i < n; i += K1_THREADS) {
+            if (t_out) t_out[ray * n + i] = ts[i];
+            if (delta_out)                                         // ray.py:62-65
+                delta_out[ray * n + i] = __fmul_rn(i + 1 < n ? __fsub_rn(ts[i + 1], ts[i]) : 1e10f, len);
+            if (rx_out) {
+                rx_out[(ray * n + i) * 3 + 0] = px[i];
+                rx_out[(ray * n + i) * 3 + 1] = py[i];
+                rx_out[(ray * n + i) * 3 + 2] = pz[i];
+            }
+        }
+        if (phi_x) encode_tile(kx, nx, tx, px, py, pz, n, tile, phi_x + (size_t)ray * n * Ex);
+        if (phi_d) {
+            __syncthreads();
+            if (threadIdx.x == 0) { px[0] = dx; py[0] = dy; pz[0] = dz; }
+            __syncthreads();
+            encode_tile(kd, nd, td, px, py, pz, 1, tile, phi_d + (size_t)ray * Ed);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(K1_THREADS) void encode_points_kernel(
+    const float* __restrict__ v, int64_t n_points, int kind, int n, const float* __restrict__ table,
+    float* __restrict__ phi) {
+    __shared__ float tile[K1_TILE_FLOATS];
+    __shared__ float px[K1_THREADS], py[K1_THREADS], pz[K1_THREADS];
+    const int E = enc_width(kind, n);
+    const int64_t n_tiles = (n_points + K1_THREADS - 1) / K1_THREADS;
+    for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        const int64_t p0 = tl * K1_THREADS;
+        const int count = (int)min((int64_t)K1_THREADS, n_points - p0);
+        if ((int)threadIdx.x < count) {
+            px[threadIdx.x] = v[(p0 + threadIdx.x) * 3 + 0];
+            py[threadIdx.x] = v[(p0 + threadIdx.x) * 3 + 1];
+            pz[threadIdx.x] = v[(p0 + threadIdx.x) * 3 + 2];
+        }
+        __syncthreads();
+        encode_tile(kind, n, table, px, py, pz, count, tile, phi + (size_t)p0 * E);
+        __syncthreads();
+    }
+}
+
+static int check_encoder(int kind, int n, const float* table, const char* which) {
+    NERFX_REQUIRE(kind == NERFX_ENC_POSITIONAL || kind == NERFX_ENC_FOURIER, "%s: unknown encoder kind %d", which, kind);
+    NERFX_REQUIRE(n >= 1 && n <= 1024, "%s: encoder size %d out of range [1, 1024]", which, n);
+    NERFX_REQUIRE(table != nullptr, "%s: encoder table is NULL", which);
+    NERFX_REQUIRE(enc_width(kind, n) <= K1_TILE_FLOATS, "%s: encoding too wide", which);
+    return 0;
+}
+
+}  // namespace nerfx
+
+using namespace nerfx;
+
+extern "C" int nerfx_sample_encode_fwd(const float* ro, const float* rd, int64_t n_rays, float tn,
+                                       float tf, int n_samples, const float* u, int kx, int nx,
+                                       const float* tx, int kd, int nd, const float* td, float* t,
+                                       float* delta, float* rx, float* phi_x, float* phi_d,
+                                       void* stream) {
+    NERFX_REQUIRE(n_rays >= 0, "n_rays < 0");
+    NERFX_REQUIRE(n_samples >= 1 && n_samples <= K1_MAX_SAMPLES, "n_samples %d out of range [1, %d]",
+                  n_samples, K1_MAX_SAMPLES);
+    NERFX_REQUIRE(tf > tn, "tf must be > tn");                      // renderer.py:164
+    if (n_rays == 0) return 0;
+    NERFX_REQUIRE(ro && rd, "ro / rd is NULL");
+    if (phi_x) { int e = check_encoder(kx, nx, tx, "phi_x"); if (e) return e; }
+    if (phi_d) { int e = check_encoder(kd, nd, td, "phi_d"); if (e) return e; }
+    const int grid = (int)std::min<int64_t>(n_rays, 256 * 16);
+    hipLaunchKernelGGL(sample_encode_kernel, dim3(grid), dim3(K1_THREADS), 0, (hipStream_t)stream, ro, rd,
+                       n_rays, tn, tf, n_samples, u, kx, nx, tx, kd, nd, td, t, delta, rx, phi_x, phi_d);
+    return launch_status("sample_encode_kernel");
+}
+
+extern "C" int nerfx_encode_fwd(const float* v, int64_t n_points, int kind, int n, const float* table,
+                                float* phi, void* stream) {
+    NERFX_REQUIRE(n_points >= 0, "n_points < 0");
+    if (n_points == 0) return 0;
+    NERFX_REQUIRE(v && phi, "v / phi is NULL");
+    { int e = check_encoder(kind, n, table, "encode"); if (e) return e; }
+    const int64_t tiles = (n_points + K1_THREADS - 1) / K1_THREADS;
+    const int grid = (int)std::min<int64_t>(tiles, 256 * 16);
+    hipLaunchKernelGGL(encode_points_kernel, dim3(grid), dim3(K1_THREADS), 0, (hipStream_t)stream, v,
+                       n_points, kind, n, table, phi);
+    return launch_status("encode_points_kernel");
+}

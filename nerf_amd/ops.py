@@ -1,0 +1,314 @@
+"""Tensor-level wrappers over the C ABI: validate, allocate outputs with torch,
+pass raw device pointers and the current HIP stream.  No arithmetic happens here.
+"""
+import ctypes as C
+import weakref
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import lib, check
+
+_PRECISION_OVERRIDE = None       # None | "fp32" | "bf16"
+
+
+def set_precision(mode: Optional[str]) -> None:
+    """Force the MLP arithmetic ("fp32" / "bf16"); None = follow torch autocast."""
+    global _PRECISION_OVERRIDE
+    assert mode in (None, "fp32", "bf16")
+    _PRECISION_OVERRIDE = mode
+
+
+def precision() -> int:
+    """bf16 MFMA when the caller is inside `torch.autocast` (the reference's --amp
+    switch, train.py:75, infer.py:132), exact fp32 MFMA otherwise."""
+    if _PRECISION_OVERRIDE is not None:
+        return _lib.PREC_BF16 if _PRECISION_OVERRIDE == "bf16" else _lib.PREC_FP32
+    return _lib.PREC_BF16 if torch.is_autocast_enabled() else _lib.PREC_FP32
+
+
+def _dev(t: Tensor, name: str, dtype=torch.float32) -> Tensor:
+    if not isinstance(t, Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"nerf_amd runs on ROCm devices only: `{name}` is on {t.device}")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- encoders ----------------------------------------------------------------
+def encode(v: Tensor, kind: int, n: int, table: Tensor) -> Tensor:
+    v = _dev(v, "v")
+    table = _dev(table, "table")
+    assert v.shape[-1] == 3, "encoders take 3-vectors"
+    width = 3 + 6 * n if kind == _lib.ENC_POSITIONAL else 2 * n
+    flat = v.reshape(-1, 3)
+    out = torch.empty((flat.shape[0], width), device=v.device, dtype=torch.float32)
+    with torch.cuda.device(v.device):
+        check(lib.nerfx_encode_fwd(_p(flat), flat.shape[0], kind, n, _p(table), _p(out), _stream()))
+    return out.reshape(*v.shape[:-1], width)
+
+
+def sample_encode(ro: Tensor, rd: Tensor, tn: float, tf: float, n: int, u: Optional[Tensor] = None,
+                  enc_x=None, enc_d=None, want_rx: bool = True):
+    """K1 standalone.  enc_x / enc_d = (kind, n, table) or None.
+    -> dict(t, delta, rx, phi_x, phi_d)."""
+    ro, rd = _dev(ro, "ro"), _dev(rd, "rd")
+    B = ro.shape[0]
+    u = None if u is None else _dev(u, "u")
+    dev = ro.device
+    out = {"t": torch.empty((B, n), device=dev), "delta": torch.empty((B, n), device=dev),
+           "rx": torch.empty((B, n, 3), device=dev) if want_rx else None, "phi_x": None, "phi_d": None}
+    kx = nx = kd = nd = 0
+    tx = td = None
+    if enc_x is not None:
+        kx, nx, tx = enc_x[0], enc_x[1], _dev(enc_x[2], "enc_x table")
+        out["phi_x"] = torch.empty((B, n, 3 + 6 * nx if kx == 0 else 2 * nx), device=dev)
+    if enc_d is not None:
+        kd, nd, td = enc_d[0], enc_d[1], _dev(enc_d[2], "enc_d table")
+        out["phi_d"] = torch.empty((B, 3 + 6 * nd if kd == 0 else 2 * nd), device=dev)
+    with torch.cuda.device(dev):
+        check(lib.nerfx_sample_encode_fwd(_p(ro), _p(rd), B, tn, tf, n, _p(u), kx, nx, _p(tx), kd, nd, _p(td),
+                                          _p(out["t"]), _p(out["delta"]), _p(out["rx"]), _p(out["phi_x"]),
+                                          _p(out["phi_d"]), _stream()))
+    return out
+
+
+# ---- compositing ----------------------------------------------------------------
+def composite_fwd(sigma: Tensor, rgb: Optional[Tensor], t: Optional[Tensor], rd: Optional[Tensor],
+                  delta: Optional[Tensor] = None, want_depth: bool = True):
+    sigma = _dev(sigma, "sigma")
+    B, n = sigma.shape
+    rgb = None if rgb is None else _dev(rgb, "rgb")
+    t = None if t is None else _dev(t, "t")
+    rd = None if rd is None else _dev(rd, "rd")
+    delta = None if delta is None else _dev(delta, "delta")
+    dev = sigma.device
+    w = torch.empty((B, n), device=dev)
+    rgb_map = torch.empty((B, 3), device=dev) if rgb is not None else None
+    depth = torch.empty((B,), device=dev) if (t is not None and want_depth) else None
+    with torch.cuda.device(dev):
+        check(lib.nerfx_composite_fwd(_p(sigma), _p(rgb), _p(t), _p(rd), _p(delta), B, n, _p(w), _p(rgb_map),
+                                      _p(depth), _stream()))
+    return w, rgb_map, depth
+
+
+def composite_bwd(sigma, rgb, t, rd, delta, g_rgb_map, g_depth, g_weights):
+    sigma = _dev(sigma, "sigma")
+    B, n = sigma.shape
+    rgb = None if rgb is None else _dev(rgb, "rgb")
+    t = None if t is None else _dev(t, "t")
+    rd = None if rd is None else _dev(rd, "rd")
+    delta = None if delta is None else _dev(delta, "delta")
+    g_rgb_map = None if g_rgb_map is None else _dev(g_rgb_map, "g_rgb_map")
+    g_depth = None if g_depth is None else _dev(g_depth, "g_depth")
+    g_weights = None if g_weights is None else _dev(g_weights, "g_weights")
+    g_sigma = torch.empty_like(sigma)
+    g_rgb = torch.empty_like(rgb) if rgb is not None else None
+    with torch.cuda.device(sigma.device):
+        check(lib.nerfx_composite_bwd(_p(sigma), _p(rgb), _p(t), _p(rd), _p(delta), B, n, _p(g_rgb_map),
+                                      _p(g_depth), _p(g_weights), _p(g_sigma), _p(g_rgb), _stream()))
+    return g_sigma, g_rgb
+
+
+# ---- hierarchical sampling --------------------------------------------------------
+def pdf_sample(t_c: Tensor, w_c: Tensor, nf: int, u: Optional[Tensor] = None, debug: bool = False):
+    """-> t_sorted (B, nc+nf)  [, cdf (B, nc-1), idx int64 (B, nf), t_pdf (B, nf) if debug]."""
+    t_c, w_c = _dev(t_c, "t_c"), _dev(w_c, "w_c")
+    B, nc = t_c.shape
+    u = None if u is None else _dev(u, "u")
+    dev = t_c.device
+    ts = torch.empty((B, nc + nf), device=dev)
+    cdf = idx = tp = None
+    if debug:
+        cdf = torch.empty((B, nc - 1), device=dev)
+        idx = torch.empty((B, nf), device=dev, dtype=torch.int64)
+        tp = torch.empty((B, nf), device=dev)
+    with torch.cuda.device(dev):
+        check(lib.nerfx_pdf_sample(_p(t_c), _p(w_c), B, nc, nf, _p(u), _p(ts), _p(cdf), _p(idx), _p(tp), _stream()))
+    return (ts, cdf, idx, tp) if debug else ts
+
+
+def searchsorted_right(cdf: Tensor, u: Tensor) -> Tensor:
+    cdf, u = _dev(cdf, "cdf"), _dev(u, "u")
+    idx = torch.empty(u.shape, device=u.device, dtype=torch.int64)
+    with torch.cuda.device(u.device):
+        check(lib.nerfx_searchsorted_right(_p(cdf), _p(u), cdf.shape[0], cdf.shape[1], u.shape[1], _p(idx), _stream()))
+    return idx
+
+
+# ---- model handles ------------------------------------------------------------------
+_ACTS = {"ReLU": _lib.ACT_RELU, "LeakyReLU": _lib.ACT_LEAKY_RELU, "SiLU": _lib.ACT_SILU}
+
+
+def _activation_code(module) -> int:
+    act = module.fc_1[0][1]
+    name = getattr(act, "original_name", type(act).__name__)      # ScriptModule or nn.Module
+    if name not in _ACTS:
+        raise NotImplementedError(f"hidden activation {name} has no HIP kernel (ReLU / LeakyReLU / SiLU)")
+    if name == "LeakyReLU" and abs(float(getattr(act, "negative_slope", 0.01)) - 0.01) > 1e-12:
+        raise NotImplementedError("LeakyReLU kernels use the default negative_slope=0.01")
+    return _ACTS[name]
+
+
+def _encoder_spec(enc) -> Tuple[int, int, Tensor]:
+    bufs = dict(enc.named_buffers())
+    if "freq_bands" in bufs:
+        return _lib.ENC_POSITIONAL, bufs["freq_bands"].numel(), bufs["freq_bands"]
+    if "b" in bufs:
+        return _lib.ENC_FOURIER, bufs["b"].shape[0], bufs["b"]
+    raise NotImplementedError("encoder must hold a `freq_bands` or `b` buffer")
+
+
+class ModelHandle:
+    """Owns a nerfx_model_t: packed copies of one module's weights on one device.
+    Works for `nerf_amd.core.NeRF` and for a `torch.jit.load`ed reference model
+    (same state_dict keys)."""
+
+    def __init__(self, module):
+        sd = dict(module.named_parameters())
+        hd = 0
+        while f"fc_1.{hd}.0.weight" in sd:
+            hd += 1
+        width = sd["fc_1.0.0.weight"].shape[0]
+        kx, nx, tx = _encoder_spec(module.phi_x)
+        kd, nd, td = _encoder_spec(module.phi_d)
+        e_x = 3 + 6 * nx if kx == _lib.ENC_POSITIONAL else 2 * nx
+        self.desc = _lib.ModelDesc(kx, nx, kd, nd, width, 2 * hd, _activation_code(module),
+                                   int(sd["fc_2.0.0.weight"].shape[1] == width + e_x))
+        keys = [f"fc_1.{i}.0" for i in range(hd)] + [f"fc_2.{i}.0" for i in range(hd)]
+        keys += ["sigma.0", "features", "rgb.0", "rgb.2"]
+        self._sources = [tx, td] + [sd[f"{k}.{w}"] for k in keys for w in ("weight", "bias")]
+        self.device = sd["fc_1.0.0.weight"].device
+        if self.device.type != "cuda":
+            raise RuntimeError(f"nerf_amd runs on ROCm devices only: the model is on {self.device}")
+        self._ptr = C.c_void_p()
+        self._stamp = None
+        tensors, arr = self._gather()
+        with torch.cuda.device(self.device):
+            check(lib.nerfx_model_create(C.byref(self.desc), arr, len(tensors), _stream(), C.byref(self._ptr)))
+        self._stamp = self._current_stamp()
+
+    def _gather(self):
+        tensors = [_dev(t.detach(), "weight") for t in self._sources]
+        arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        return tensors, arr
+
+    def _current_stamp(self):
+        return tuple((t.data_ptr(), t._version) for t in self._sources)
+
+    def sync(self) -> "ModelHandle":
+        """Re-pack if any source tensor was written (optimizer step, load_state_dict)."""
+        stamp = self._current_stamp()
+        if stamp != self._stamp:
+            tensors, arr = self._gather()
+            with torch.cuda.device(self.device):
+                check(lib.nerfx_model_refresh(self._ptr, arr, len(tensors), _stream()))
+            self._stamp = stamp
+        return self
+
+    @property
+    def ptr(self):
+        return self._ptr
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                lib.nerfx_model_destroy(self._ptr)
+                self._ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
+_HANDLES = weakref.WeakKeyDictionary()
+
+
+def handle_for(module) -> ModelHandle:
+    h = _HANDLES.get(module)
+    dev = next(module.parameters()).device
+    if h is None or h.device != dev:
+        h = ModelHandle(module)
+        _HANDLES[module] = h
+    return h.sync()
+
+
+# ---- MLP --------------------------------------------------------------------------------
+def mlp_points(handle: ModelHandle, x: Tensor, d: Tensor, density_only: bool = False, prec: Optional[int] = None):
+    x, d = _dev(x, "rx").reshape(-1, 3), _dev(d, "rd").reshape(-1, 3)
+    assert x.shape == d.shape, "positions and directions must pair up"
+    M = x.shape[0]
+    sigma = torch.empty((M,), device=x.device)
+    rgb = None if density_only else torch.empty((M, 3), device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.nerfx_mlp_fwd_points(handle.ptr, precision() if prec is None else prec, _p(x), _p(d), M,
+                                       _p(sigma), _p(rgb), _stream()))
+    return sigma, rgb
+
+
+def mlp_rays(handle: ModelHandle, ro: Tensor, rd: Tensor, t: Tensor, density_only: bool = False,
+             prec: Optional[int] = None):
+    ro, rd, t = _dev(ro, "ro"), _dev(rd, "rd"), _dev(t, "t")
+    B, n = t.shape
+    sigma = torch.empty((B, n), device=t.device)
+    rgb = None if density_only else torch.empty((B, n, 3), device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.nerfx_mlp_fwd_rays(handle.ptr, precision() if prec is None else prec, _p(ro), _p(rd), _p(t), B, n,
+                                     _p(sigma), _p(rgb), _stream()))
+    return sigma, rgb
+
+
+# ---- fused render -------------------------------------------------------------------------
+def render(coarse: ModelHandle, fine: Optional[ModelHandle], ro: Tensor, rd: Tensor, tn: float, tf: float,
+           nc: int, nf: int, u_c: Optional[Tensor] = None, u_f: Optional[Tensor] = None,
+           prec: Optional[int] = None):
+    ro, rd = _dev(ro, "ro"), _dev(rd, "rd")
+    B, n, dev = ro.shape[0], nc + nf, ro.device
+    u_c = None if u_c is None else _dev(u_c, "u_c")
+    u_f = None if u_f is None else _dev(u_f, "u_f")
+    t = torch.empty((B, n), device=dev)
+    w = torch.empty((B, n), device=dev)
+    depth = torch.empty((B,), device=dev)
+    rgb_map = torch.empty((B, 3), device=dev)
+    ws_bytes = lib.nerfx_render_workspace_bytes(B, nc, nf)
+    ws = torch.empty((max(ws_bytes, 1),), device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        check(lib.nerfx_render_fwd(coarse.ptr, None if fine is None else fine.ptr,
+                                   precision() if prec is None else prec, _p(ro), _p(rd), B, tn, tf, nc, nf,
+                                   _p(u_c), _p(u_f), _p(ws), ws_bytes, _p(t), _p(w), _p(depth), _p(rgb_map), _stream()))
+    return t, w, depth, rgb_map
+
+
+# ---- module-level entry points used by nerf_amd.core ------------------------------------------
+def segment_lengths(t: Tensor, rd: Tensor) -> Tensor:
+    t, rd = _dev(t, "t"), _dev(rd, "rd")
+    delta = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        check(lib.nerfx_segment_lengths(_p(t), _p(rd), t.shape[0], t.shape[1], _p(delta), _stream()))
+    return delta
+
+
+def _wants_grad(module) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+def field_forward(module, rx: Tensor, rd: Tensor):
+    """NeRF.forward: sigma (M,), rgb (..., 3)."""
+    if _wants_grad(module):
+        raise NotImplementedError("gradients through NeRF.forward are not built yet: call under torch.no_grad()")
+    sigma, rgb = mlp_points(handle_for(module), rx, rd)
+    return sigma, rgb.reshape(*rx.shape[:-1], 3)
+
+
+def render_train(coarse, fine, ro, rd, tn, tf, nc, nf, u_c, u_f):
+    raise NotImplementedError("render_volume(train=True) needs the MLP backward kernels, which are not built yet")

@@ -1,0 +1,361 @@
+"""Parity tests proper: every HIP kernel, called through the C ABI (ctypes), against the
+golden vectors of the reference and against the CPU oracle on seeded inputs.
+
+Tolerances (from the acceptance criteria of the path):
+  * searchsorted indices: bit-exact given identical cdf / u;
+  * sample positions, encodings, composited rgb / depth in fp32: 1e-5 relative;
+  * bf16-MFMA outputs: 1e-2 absolute on rgb.
+"""
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from helpers import assert_close, oracle_model, product_model
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import nerf_amd.ops as ops_
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return ops_
+
+
+def dev(x):
+    return x.cuda()
+
+
+# ---- K1 -----------------------------------------------------------------------------
+def test_k1_sampling_golden(ops):
+    meta, g = load_golden("g1_sampling")
+    ro, rd = dev(g["ro"]), dev(g["rd"])
+    for tag, u in (("det", None), ("pert", dev(g["pert_u"]))):
+        out = ops.sample_encode(ro, rd, meta["tn"], meta["tf"], meta["n"], u)
+        assert_close(out["t"].cpu(), g[f"{tag}_t"], rtol=1e-6, atol=0, what=f"{tag} t")
+        assert_close(out["delta"].cpu(), g[f"{tag}_delta"], rtol=1e-5, atol=1e-7, what=f"{tag} delta")
+        assert_close(out["rx"].cpu(), g[f"{tag}_rx"], rtol=1e-5, atol=1e-6, what=f"{tag} rx")
+    a = meta["alt"]
+    out = ops.sample_encode(ro, rd, a["tn"], a["tf"], a["n"], None)
+    assert_close(out["t"].cpu(), g["alt_t"], rtol=1e-6, atol=0, what="alt t")
+    assert_close(out["rx"].cpu(), g["alt_rx"], rtol=1e-5, atol=1e-6, what="alt rx")
+    assert_close(out["delta"].cpu(), g["alt_delta"], rtol=1e-5, atol=1e-7, what="alt delta")
+
+
+def test_k1_fused_encodings(ops):
+    """sample + encode in one launch == oracle sampling followed by oracle encoding."""
+    meta, g = load_golden("g1_sampling")
+    f6, f4 = O.positional_freq_bands(6), O.positional_freq_bands(4)
+    out = ops.sample_encode(dev(g["ro"]), dev(g["rd"]), 2.0, 6.0, 64, dev(g["pert_u"]),
+                            enc_x=(0, 6, dev(f6)), enc_d=(0, 4, dev(f4)))
+    want_x = O.encode_positional(g["pert_rx"], f6)
+    want_d = O.encode_positional(g["rd"], f4)
+    assert out["phi_x"].shape == (16, 64, 39) and out["phi_d"].shape == (16, 27)
+    assert_close(out["phi_x"].cpu(), want_x, rtol=1e-5, atol=2e-5, what="phi_x")   # |arg| <= 224: 1 ulp of arg = 1.5e-5
+    assert_close(out["phi_d"].cpu(), want_d, rtol=1e-5, atol=1e-6, what="phi_d")
+
+
+def test_encoders_golden(ops):
+    _, g = load_golden("g2_encodings")
+    for L in (4, 6, 10):
+        f = dev(g[f"pe{L}_freq"])
+        got = ops.encode(dev(g["v_unit"]), 0, L, f).cpu()
+        assert_close(got, g[f"pe{L}_unit"], rtol=1e-5, atol=1e-6, what=f"pe{L} unit")
+        # far points: the argument f*v is identical (one fp32 rounding); sin/cos differ by libm ulps
+        got = ops.encode(dev(g["v_far"]), 0, L, f).cpu()
+        assert_close(got, g[f"pe{L}_far"], rtol=1e-5, atol=1e-6, what=f"pe{L} far")
+    b = dev(g["ff_b"])
+    got = ops.encode(dev(g["v_unit"]), 1, 64, b).cpu()
+    # Fourier angles reach |a| ~ 2 pi * 3 * 8 * 3: the 3-term dot product's rounding order moves
+    # the angle by ~1 ulp(a) ~ 3e-5, which is the floor for any fp32 implementation.
+    assert_close(got, g["ff_unit"], rtol=1e-5, atol=1e-4, what="ff unit")
+    got = ops.encode(dev(g["v_far"]), 1, 64, b).cpu()
+    assert_close(got, g["ff_far"], rtol=1e-5, atol=2e-3, what="ff far")
+    # empty input
+    assert ops.encode(torch.empty(0, 3, device="cuda"), 0, 6, dev(g["pe6_freq"])).shape == (0, 39)
+
+
+# ---- K3 -----------------------------------------------------------------------------
+def test_k3_composite_golden(ops):
+    _, g = load_golden("g4_composite")
+    sigma, rgb, t, rd, delta = (dev(g[k]) for k in ("sigma", "rgb", "t", "rd", "delta"))
+    for kw in (dict(delta=None), dict(delta=delta)):
+        w, rgb_map, depth = ops.composite_fwd(sigma, rgb, t, rd, **kw)
+        assert_close(w.cpu(), g["weights"], rtol=1e-5, atol=1e-9, what="weights")
+        assert_close(rgb_map.cpu(), g["rgb_map"], rtol=1e-5, atol=1e-7, what="rgb_map")
+        assert_close(depth.cpu(), g["depth"], rtol=1e-5, atol=1e-7, what="depth")
+    w, none, _ = ops.composite_fwd(sigma, None, t, rd)
+    assert none is None
+    assert_close(w.cpu(), g["weights"], rtol=1e-5, atol=1e-9, what="weights only")
+    w65, rgb65, _ = ops.composite_fwd(sigma[:, :65].contiguous(), rgb[:, :65].contiguous(),
+                                      t[:, :65].contiguous(), rd)
+    assert_close(w65.cpu(), g["w65"], rtol=1e-5, atol=1e-9, what="w65")
+    assert_close(rgb65.cpu(), g["rgb65"], rtol=1e-5, atol=1e-7, what="rgb65")
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 128, 192, 200, 333, 512])
+def test_k3_composite_sizes_and_backward(ops, n):
+    gen = torch.Generator().manual_seed(n)
+    B = 37
+    sigma = (torch.rand(B, n, generator=gen) * 2).requires_grad_(True)
+    rgb = torch.rand(B, n, 3, generator=gen).requires_grad_(True)
+    t, _ = torch.sort(torch.rand(B, n, generator=gen) * 4 + 2, dim=-1)
+    rd = torch.rand(B, 3, generator=gen) + 0.1
+    delta = O.segment_lengths(t, rd)
+    w, rgb_map = O.raymarch_volume(sigma, rgb, delta)
+    depth = (w * t).sum(-1)
+    g_rgb_map = torch.randn(B, 3, generator=gen)
+    g_depth = torch.randn(B, generator=gen)
+    g_w = torch.randn(B, n, generator=gen)
+    (rgb_map * g_rgb_map).sum().add((depth * g_depth).sum()).add((w * g_w).sum()).backward()
+    got_w, got_rgb_map, got_depth = ops.composite_fwd(dev(sigma.detach()), dev(rgb.detach()), dev(t), dev(rd))
+    assert_close(got_w.cpu(), w.detach(), rtol=1e-5, atol=1e-8, what="weights")
+    assert_close(got_rgb_map.cpu(), rgb_map.detach(), rtol=1e-5, atol=1e-7, what="rgb_map")
+    assert_close(got_depth.cpu(), depth.detach(), rtol=1e-5, atol=1e-6, what="depth")
+    gs, gr = ops.composite_bwd(dev(sigma.detach()), dev(rgb.detach()), dev(t), dev(rd), None,
+                               dev(g_rgb_map), dev(g_depth), dev(g_w))
+    scale = sigma.grad.abs().max().item()
+    assert_close(gs.cpu(), sigma.grad, rtol=1e-4, atol=1e-5 * scale, what="g_sigma")
+    assert_close(gr.cpu(), rgb.grad, rtol=1e-5, atol=1e-7, what="g_rgb")
+    # rgb-only loss, as in training (train.py:76-77)
+    gs2, _ = ops.composite_bwd(dev(sigma.detach()), dev(rgb.detach()), dev(t), dev(rd), None, dev(g_rgb_map), None, None)
+    sigma.grad = None
+    w2, rm2 = O.raymarch_volume(sigma, rgb.detach(), delta)
+    (rm2 * g_rgb_map).sum().backward()
+    assert_close(gs2.cpu(), sigma.grad, rtol=1e-4, atol=1e-5 * sigma.grad.abs().max().item(), what="g_sigma rgb-only")
+
+
+def test_segment_lengths(ops):
+    _, g = load_golden("g4_composite")
+    assert_close(ops.segment_lengths(dev(g["t"]), dev(g["rd"])).cpu(), g["delta"], rtol=1e-6, atol=0)
+
+
+# ---- K4 -----------------------------------------------------------------------------
+def test_k4_searchsorted_bit_exact(ops):
+    _, g = load_golden("g5_pdf")
+    for tag in ("det", "pert"):
+        idx = ops.searchsorted_right(dev(g["cdf"]), dev(g[f"{tag}_u"])).cpu()
+        assert torch.equal(idx, g[f"{tag}_idx"])
+    assert torch.equal(ops.searchsorted_right(dev(g["ss_cdf"]), dev(g["ss_u"])).cpu(), g["ss_idx"])
+    # large random case against the oracle's counting definition
+    gen = torch.Generator().manual_seed(5)
+    cdf, _ = torch.sort(torch.rand(4096, 63, generator=gen), dim=-1)
+    cdf[:, 0] = 0
+    u = torch.rand(4096, 64, generator=gen)
+    u[:, ::7] = cdf[:, 3:4]                                  # exact hits
+    assert torch.equal(ops.searchsorted_right(dev(cdf), dev(u)).cpu(), O.searchsorted_right(cdf, u))
+
+
+def test_k4_pdf_sample_golden(ops):
+    meta, g = load_golden("g5_pdf")
+    t_c, w_c = dev(g["t"]), dev(g["w"])
+    for tag in ("det", "pert"):
+        u = None if tag == "det" else dev(g["pert_u"])
+        ts, cdf, idx, tp = ops.pdf_sample(t_c, w_c, meta["nf"], u, debug=True)
+        assert_close(cdf.cpu(), g["cdf"], rtol=1e-5, atol=2e-7, what="cdf")
+        # indices are exact for the cdf the kernel itself produced
+        assert torch.equal(idx.cpu(), O.searchsorted_right(cdf.cpu(), g[f"{tag}_u"]))
+        # ... and agree with the reference's wherever its cdf does not put u within an ulp of a knot
+        same = idx.cpu() == g[f"{tag}_idx"]
+        assert same.float().mean().item() > 0.99
+        assert_close(tp.cpu(), g[f"{tag}_t_pdf"], rtol=1e-5, atol=1e-5, what="t_pdf")
+        assert_close(ts.cpu(), g[f"{tag}_t_sorted"], rtol=1e-5, atol=1e-5, what="t_sorted")
+        assert bool((ts[:, 1:] >= ts[:, :-1]).all())
+        only = ops.pdf_sample(t_c, w_c, meta["nf"], u)
+        assert torch.equal(only, ts)
+
+
+@pytest.mark.parametrize("nc,nf", [(3, 1), (40, 24), (64, 128), (33, 77), (256, 256)])
+def test_k4_pdf_sample_sizes(ops, nc, nf):
+    gen = torch.Generator().manual_seed(nc * 1000 + nf)
+    B = 29
+    t = torch.linspace(2, 6, nc).expand(B, nc).contiguous()
+    w = torch.rand(B, nc, generator=gen) ** 3
+    for u in (None, torch.rand(B, nf, generator=gen)):
+        want = O.pdf_rays(torch.zeros(B, 3), torch.ones(B, 3), t, w, nf, u)[2]
+        got = ops.pdf_sample(dev(t), dev(w), nf, None if u is None else dev(u)).cpu()
+        assert_close(got, want, rtol=1e-5, atol=1e-5, what=f"t_sorted {nc}+{nf}")
+
+
+# ---- K2 -----------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("g3_mlp_"))
+def test_k2_mlp_golden_fp32(ops, name):
+    meta, g = load_golden(name)
+    model = product_model(meta, g)
+    with torch.no_grad():
+        ops.set_precision("fp32")
+        sigma, rgb = model(dev(g["rx"]), dev(g["rd"]))
+    fourier = meta["enc_x"][0] == "ff"
+    # Fourier angles are O(1e3): one ulp of the angle is ~1e-4, amplified by the trunk.
+    rtol, atol = (2e-3, 2e-3) if fourier else (1e-5, 2e-6)
+    assert sigma.shape == g["sigma"].shape and rgb.shape == g["rgb"].shape
+    assert_close(sigma.cpu(), g["sigma"], rtol=rtol, atol=atol, what="sigma")
+    assert_close(rgb.cpu(), g["rgb"], rtol=rtol, atol=atol, what="rgb")
+    ops.set_precision(None)
+
+
+@pytest.mark.parametrize("name", golden_names("g3_mlp_"))
+def test_k2_mlp_golden_bf16(ops, name):
+    meta, g = load_golden(name)
+    model = product_model(meta, g)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        sigma, rgb = model(dev(g["rx"]), dev(g["rd"]))
+    assert_close(rgb.cpu(), g["rgb"], rtol=0, atol=1e-2, what="rgb")
+    assert_close(sigma.cpu(), g["sigma"], rtol=3e-2, atol=1e-2, what="sigma")
+
+
+@pytest.mark.parametrize("M", [1, 31, 32, 33, 255, 257, 5000])
+def test_k2_mlp_ragged_sizes(ops, M):
+    """Tails of a 32-sample wave / 256-sample block, density-only mode, and the ray form."""
+    meta, g = load_golden("g3_mlp_base")
+    model = product_model(meta, g)
+    om = oracle_model(meta, g)
+    gen = torch.Generator().manual_seed(M)
+    x = (torch.rand(M, 3, generator=gen) * 2 - 1) * 3
+    d = torch.rand(M, 3, generator=gen) * 2 - 1
+    want_s, want_c = om(x, d)
+    h = ops.handle_for(model)
+    for prec, (rt, at) in ((0, (1e-5, 2e-6)), (1, (3e-2, 1e-2))):
+        s, c = ops.mlp_points(h, dev(x), dev(d), prec=prec)
+        assert_close(s.cpu(), want_s, rtol=rt, atol=at, what=f"sigma prec{prec}")
+        assert_close(c.cpu(), want_c, rtol=rt, atol=at, what=f"rgb prec{prec}")
+        s2, none = ops.mlp_points(h, dev(x), dev(d), density_only=True, prec=prec)
+        assert none is None
+        assert_close(s2.cpu(), want_s, rtol=rt, atol=at, what=f"sigma-only prec{prec}")
+    # ray form: positions ro + rd * t formed in the kernel
+    B, n = max(M // 5, 1), 5
+    ro, rd = torch.rand(B, 3, generator=gen), torch.rand(B, 3, generator=gen)
+    t = torch.rand(B, n, generator=gen) * 4 + 2
+    rx = ro[:, None, :] + rd[:, None, :] * t[:, :, None]
+    want_s, want_c = om(rx, rd[:, None, :].expand(-1, n, -1))
+    s, c = ops.mlp_rays(h, dev(ro), dev(rd), dev(t), prec=0)
+    assert_close(s.cpu().view(-1), want_s, rtol=1e-5, atol=2e-6, what="ray-form sigma")
+    assert_close(c.cpu(), want_c, rtol=1e-5, atol=2e-6, what="ray-form rgb")
+
+
+def test_k2_weight_refresh(ops):
+    """In-place weight updates (an optimizer step) are picked up on the next call."""
+    meta, g = load_golden("g3_mlp_student")
+    model = product_model(meta, g)
+    x, d = dev(g["rx"]), dev(g["rd"])
+    with torch.no_grad():
+        ops.set_precision("fp32")
+        s0, _ = model(x, d)
+        model.sigma[0].bias.add_(0.5)
+        s1, _ = model(x, d)
+        ops.set_precision(None)
+    assert not torch.allclose(s0, s1)
+    om = oracle_model(meta, g)
+    om.params["sigma.0.bias"] = om.params["sigma.0.bias"] + 0.5
+    assert_close(s1.cpu(), om(g["rx"], g["rd"])[0], rtol=1e-5, atol=2e-6)
+
+
+# ---- the boundary: render_volume -----------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("g6_render_"))
+def test_render_volume_golden(ops, name):
+    from nerf_amd.core import BoundedVolumeRaymarcher
+    meta, g = load_golden(name)
+    coarse = product_model(meta["coarse"], g, "c_")
+    fine = coarse if meta["fine"]["name"] == meta["coarse"]["name"] else product_model(meta["fine"], g, "f_")
+    bvr = BoundedVolumeRaymarcher(meta["tn"], meta["tf"], meta["nc"], meta["nf"])
+    assert bvr.samples == meta["nc"] + meta["nf"]
+    ro, rd = dev(g["ro"]), dev(g["rd"])
+    fourier = meta["coarse"]["enc_x"][0] == "ff"
+    rtol, atol = (5e-3, 5e-3) if fourier else (1e-5, 1e-5)
+    ops.set_precision("fp32")
+    t, w, depth, rgb = bvr.render_volume(coarse, fine, ro, rd)
+    ops.set_precision(None)
+    assert t.shape == g["det_t"].shape and w.shape == g["det_w"].shape
+    assert depth.shape == g["det_depth"].shape and rgb.shape == g["det_rgb"].shape
+    assert_close(t.cpu(), g["det_t"], rtol=rtol, atol=atol, what="t")
+    assert_close(depth.cpu(), g["det_depth"], rtol=rtol, atol=atol, what="depth")
+    assert_close(rgb.cpu(), g["det_rgb"], rtol=rtol, atol=atol, what="rgb")
+    assert_close(w.cpu(), g["det_w"], rtol=10 * rtol, atol=atol, what="weights")
+    # fixed uniforms (perturb=True in the reference) through the C ABI
+    hc, hf = ops.handle_for(coarse), (ops.handle_for(fine) if meta["nf"] else None)
+    u_f = dev(g["pert_u_f"]) if meta["nf"] else None
+    t, w, depth, rgb = ops.render(hc, hf, ro, rd, meta["tn"], meta["tf"], meta["nc"], meta["nf"],
+                                  dev(g["pert_u_c"]), u_f, prec=0)
+    assert_close(t.cpu(), g["pert_t"], rtol=rtol, atol=atol, what="pert t")
+    assert_close(depth.cpu(), g["pert_depth"], rtol=rtol, atol=atol, what="pert depth")
+    assert_close(rgb.cpu(), g["pert_rgb"], rtol=rtol, atol=atol, what="pert rgb")
+    # bf16 MFMA: 1e-2 absolute on rgb
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        _, _, depth16, rgb16 = bvr.render_volume(coarse, fine, ro, rd)
+    assert_close(rgb16.cpu(), g["det_rgb"], rtol=0, atol=1e-2, what="bf16 rgb")
+    assert_close(depth16.cpu(), g["det_depth"], rtol=2e-2, atol=2e-2, what="bf16 depth")
+
+
+def test_render_perturb_uses_torch_generator(ops):
+    """perturb=True draws rand(B,Nc) then rand(B,Nf) from the device generator, coarse first."""
+    from nerf_amd.core import BoundedVolumeRaymarcher
+    meta, g = load_golden("g6_render_student_student_64_128")
+    model = product_model(meta["coarse"], g, "c_")
+    bvr = BoundedVolumeRaymarcher(2.0, 6.0, 64, 128)
+    ro, rd = dev(g["ro"]), dev(g["rd"])
+    ops.set_precision("fp32")
+    torch.manual_seed(99)
+    got = bvr.render_volume(model, model, ro, rd, perturb=True)
+    torch.manual_seed(99)
+    u_c = torch.rand(24, 64, device="cuda")
+    u_f = torch.rand(24, 128, device="cuda")
+    h = ops.handle_for(model)
+    want = ops.render(h, h, ro, rd, 2.0, 6.0, 64, 128, u_c, u_f, prec=0)
+    ops.set_precision(None)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    om = oracle_model(meta["coarse"], g, "c_")
+    with torch.no_grad():
+        ref = O.render_volume(om, om, g["ro"], g["rd"], 2.0, 6.0, 64, 128, u_c.cpu(), u_f.cpu())
+    assert_close(got[3].cpu(), ref[3], rtol=1e-5, atol=1e-5, what="rgb")
+    assert_close(got[2].cpu(), ref[2], rtol=1e-5, atol=1e-5, what="depth")
+
+
+def test_infer_golden(ops):
+    import nerf_amd.infer  # noqa: F401  (attaches NeRF.infer)
+    from nerf_amd.core import BoundedVolumeRaymarcher, NeRF
+    meta, g = load_golden("g8_infer")
+    model = product_model(meta["model"], g)
+    bvr = BoundedVolumeRaymarcher(meta["tn"], meta["tf"], meta["nc"], meta["nf"])
+    ops.set_precision("fp32")
+    depth, rgb = NeRF.infer(model, model, bvr, g["ro"], g["rd"], meta["H"], meta["W"], 100, False)
+    assert depth.device.type == "cpu" and depth.shape == (meta["H"], meta["W"], 3) and depth.dtype == torch.float32
+    assert_close(depth, g["depth"], rtol=1e-4, atol=2e-2, what="depth")       # [0,255] scale
+    assert_close(rgb, g["rgb"], rtol=1e-5, atol=3e-3, what="rgb")
+    ro_nan = g["ro"].clone()
+    ro_nan[5] = float("nan")
+    dn, cn = model.infer(model, bvr, ro_nan, g["rd"], meta["H"], meta["W"], 64, False)
+    ops.set_precision(None)
+    assert_close(dn, g["nan_depth"], rtol=1e-4, atol=2e-2, what="nan depth")
+    assert_close(cn, g["nan_rgb"], rtol=1e-5, atol=3e-3, what="nan rgb")
+
+
+def test_render_oracle_2048_rays_and_properties(ops):
+    """A batch the oracle finishes in seconds + size-independent properties at a larger size."""
+    from nerf_amd.core import BoundedVolumeRaymarcher
+    meta, g = load_golden("g3_mlp_base")
+    model = product_model(meta, g)
+    om = oracle_model(meta, g)
+    bvr = BoundedVolumeRaymarcher(2.0, 6.0, 64, 64)
+    gen = torch.Generator().manual_seed(2048)
+    ro, rd = torch.rand(2048, 3, generator=gen), torch.rand(2048, 3, generator=gen)
+    with torch.no_grad():
+        ref = O.render_volume(om, om, ro, rd, 2.0, 6.0, 64, 64)
+    ops.set_precision("fp32")
+    got = bvr.render_volume(model, model, dev(ro), dev(rd))
+    assert_close(got[0].cpu(), ref[0], rtol=1e-5, atol=1e-5, what="t")
+    assert_close(got[2].cpu(), ref[2], rtol=1e-5, atol=1e-5, what="depth")
+    assert_close(got[3].cpu(), ref[3], rtol=1e-5, atol=1e-5, what="rgb")
+    # properties on 100k rays: rays are independent (slice of render == render of slice,
+    # bit for bit), weights sum to 1, t ascending, reruns identical
+    ro, rd = torch.rand(100_000, 3, device="cuda"), torch.rand(100_000, 3, device="cuda")
+    full = bvr.render_volume(model, model, ro, rd)
+    part = bvr.render_volume(model, model, ro[30_001:47_777], rd[30_001:47_777])
+    again = bvr.render_volume(model, model, ro, rd)
+    ops.set_precision(None)
+    for a, b, c in zip(full, part, again):
+        assert torch.equal(a[30_001:47_777], b)
+        assert torch.equal(a, c)
+    assert bool((full[0][:, 1:] >= full[0][:, :-1]).all())
+    assert_close(full[1].sum(-1).cpu(), torch.ones(100_000), rtol=0, atol=1e-4, what="sum of weights")
