@@ -1,0 +1,150 @@
+"""Headline benchmark: rays/s of coarse64+fine64 rendering of 800x800 frames.
+
+    python bench.py --gpus N --steps K --warmup W [--prec bf16|fp32] [--batch RAYS]
+
+A step renders one 800x800 synthetic-ray frame per GPU (640,000 rays, U[0,1)^3 origins and
+un-normalised directions like the reference's bench, random-init NeRF(PE(3,6),PE(3,6),256,4),
+BVR(2,6,64,64), perturb off) through `BoundedVolumeRaymarcher.render_volume`, inputs and
+weights resident in HBM, outputs left on the device; for N > 1 each rank renders its own
+frame (the 40-view orbit is frame-sharded: no collective) and rank 0 gathers rgb+depth
+(16 B/ray) at the end of the step.  Rank 0 prints ONE JSON line.
+
+roofline: every launch of the fused MLP kernel inside the timed region is bracketed by HIP
+events on the launch stream; achieved = algorithmic FLOPs of those launches / their summed
+duration (so per-launch FLOPs / average launch duration), against the dense MFMA peak.
+cpu_baseline: the CPU oracle (oracle/nerf_oracle.py, torch CPU fp32) renders a 100x100
+frame of the same workload on this host's cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_FULL = 641_024          # algorithmic FLOP per sample, full network
+FLOP_DENSITY = 433_664       # algorithmic FLOP per sample, trunk + density head
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+
+
+def cpu_baseline(model, tn, tf, nc, nf):
+    from oracle import nerf_oracle as O
+    params = {k: v.detach().cpu() for k, v in model.named_parameters()}
+    f = O.positional_freq_bands(6)
+    om = O.Model(params, O.make_encoder("pe", f), O.make_encoder("pe", f), "relu", True)
+    g = torch.Generator().manual_seed(0)
+    H = W = 100
+    ro, rd = torch.rand(H * W, 3, generator=g), torch.rand(H * W, 3, generator=g)
+    O.infer(om, om, ro[:1000], rd[:1000], 10, 100, tn, tf, nc, nf, batch_size=16384)      # warm-up
+    best = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        O.infer(om, om, ro, rd, H, W, tn, tf, nc, nf, batch_size=16384)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": H * W / best, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{H}x{W} frame (10,000 rays) of the same workload via oracle.infer, best of 2, "
+                      f"{best:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--prec", choices=("bf16", "fp32"), default="bf16")
+    ap.add_argument("--batch", type=int, default=65536, help="rays per render_volume call")
+    ap.add_argument("--size", type=int, default=800, help="frame is size x size")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import nerf_amd.ops as ops
+    from nerf_amd.core import BoundedVolumeRaymarcher, NeRF, PositionalEncoding
+
+    tn, tf, nc, nf = 2.0, 6.0, 64, 64
+    torch.manual_seed(0)
+    model = NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 6), 256, 4).to(dev)
+    bvr = BoundedVolumeRaymarcher(tn, tf, nc, nf)
+    n_rays = args.size * args.size
+    g = torch.Generator(device=dev).manual_seed(rank)
+    ro = torch.rand(n_rays, 3, device=dev, generator=g)
+    rd = torch.rand(n_rays, 3, device=dev, generator=g)
+    out = torch.zeros(n_rays, 4, device=dev)                 # rgb | depth, stays on the device
+    gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    ops.set_precision(args.prec)
+
+    def step():
+        for s in range(0, n_rays, args.batch):
+            e = min(s + args.batch, n_rays)
+            *_, D, C = bvr.render_volume(model, model, ro[s:e], rd[s:e])
+            out[s:e, :3], out[s:e, 3] = C, D
+        if world > 1:
+            dist.gather(out, gathered, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        ops.PROFILE = []
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        log, ops.PROFILE = ops.PROFILE, None
+
+    t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    dt = t_max.item()
+
+    if rank == 0:
+        stage_ms, mlp_flop, mlp_launches = {}, 0.0, 0
+        for stage, b, n, colour, a, z in log:
+            stage_ms[stage] = stage_ms.get(stage, 0.0) + a.elapsed_time(z)
+            if stage == "mlp":
+                mlp_flop += b * n * (FLOP_FULL if colour else FLOP_DENSITY)
+                mlp_launches += 1
+        achieved = mlp_flop / (stage_ms["mlp"] * 1e-3) / 1e12
+        result = {
+            "metric": "rays/sec (coarse64+fine64)", "value": world * n_rays * args.steps / dt, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec,
+            "data": "synthetic",
+            "config": {"workload": f"{args.size}x{args.size} frame per GPU, NeRF(PE(3,6),PE(3,6),256,4) random init, "
+                                   f"BVR(2,6,64c+64f), perturb off, {args.batch} rays per render_volume call",
+                       "rays_per_step_per_gpu": n_rays, "parallelism": f"frame-sharded x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "mlp_fwd_kernel", "achieved": achieved,
+                         "peak": PEAK_TFLOPS[args.prec], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.prec],
+                         "traffic": None, "launches": mlp_launches,
+                         "avg_launch_ms": stage_ms["mlp"] / mlp_launches,
+                         "flop_per_launch": mlp_flop / mlp_launches},
+            "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+        }
+        if world == 1 and not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(model, tn, tf, nc, nf)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

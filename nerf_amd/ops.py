@@ -269,6 +269,35 @@ def mlp_rays(handle: ModelHandle, ro: Tensor, rd: Tensor, t: Tensor, density_onl
 
 
 # ---- fused render -------------------------------------------------------------------------
+# When set to a list, `render` issues the same kernels stage by stage through the C ABI
+# (exactly the sequence nerfx_render_fwd enqueues) with an event pair around each, and
+# appends (stage, n_rays, n_samples, colour, start_event, stop_event) records to it.
+PROFILE = None
+
+
+def _render_staged(coarse, fine, ro, rd, tn, tf, nc, nf, u_c, u_f, prec, log):
+    def timed(stage, n_samples, colour, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        log.append((stage, ro.shape[0], n_samples, colour, a, b))
+        return out
+
+    if nf == 0:
+        t = timed("sample", nc, False, lambda: sample_encode(ro, rd, tn, tf, nc, u_c, want_rx=False)["t"])
+        sigma, rgb = timed("mlp", nc, True, lambda: mlp_rays(coarse, ro, rd, t, prec=prec))
+        w, rgb_map, depth = timed("composite", nc, True, lambda: composite_fwd(sigma, rgb, t, rd))
+        return t, w, depth, rgb_map
+    t_c = timed("sample", nc, False, lambda: sample_encode(ro, rd, tn, tf, nc, u_c, want_rx=False)["t"])
+    sigma_c, _ = timed("mlp", nc, False, lambda: mlp_rays(coarse, ro, rd, t_c, density_only=True, prec=prec))
+    w_c, _, _ = timed("composite", nc, False, lambda: composite_fwd(sigma_c, None, t_c, rd, want_depth=False))
+    t = timed("pdf", nc + nf, False, lambda: pdf_sample(t_c, w_c, nf, u_f))
+    sigma, rgb = timed("mlp", nc + nf, True, lambda: mlp_rays(fine, ro, rd, t, prec=prec))
+    w, rgb_map, depth = timed("composite", nc + nf, True, lambda: composite_fwd(sigma, rgb, t, rd))
+    return t, w, depth, rgb_map
+
+
 def render(coarse: ModelHandle, fine: Optional[ModelHandle], ro: Tensor, rd: Tensor, tn: float, tf: float,
            nc: int, nf: int, u_c: Optional[Tensor] = None, u_f: Optional[Tensor] = None,
            prec: Optional[int] = None):
@@ -276,6 +305,9 @@ def render(coarse: ModelHandle, fine: Optional[ModelHandle], ro: Tensor, rd: Ten
     B, n, dev = ro.shape[0], nc + nf, ro.device
     u_c = None if u_c is None else _dev(u_c, "u_c")
     u_f = None if u_f is None else _dev(u_f, "u_f")
+    if PROFILE is not None:
+        return _render_staged(coarse, fine, ro, rd, tn, tf, nc, nf, u_c, u_f,
+                              precision() if prec is None else prec, PROFILE)
     t = torch.empty((B, n), device=dev)
     w = torch.empty((B, n), device=dev)
     depth = torch.empty((B,), device=dev)
