@@ -1,26 +1,32 @@
-// Layout shared by the weight packer (host + pack kernels) and the fused MLP
-// kernels: how a radiance field's Linear layers become one linear "unit stream".
+// Layout shared by the weight packer (model.hip) and the fused MLP kernels: how a
+// radiance field's Linear layers become one linear "unit stream".
 //
-// A UNIT is 1 KiB = 64 lanes x 16 B: the A operands (weights) one wavefront
-// reads with a single ds_read_b128 for one 32-row output tile and one k-unit
-// (16 input features in bf16, 8 in fp32).  Units are stored in exactly the
-// order the kernel consumes them -- layer by layer, k-unit by k-unit, output
-// tile by output tile -- so the kernel's LDS ring is a sliding window over a
-// flat array filled by global_load_lds, and lane l always reads unit + 16 l.
+// A UNIT is 1 KiB = 64 lanes x 16 B: the A operands (weights) one wavefront reads
+// with a single ds_read_b128 for one 32-row output tile and one k-unit (16 input
+// features in bf16, 8 in fp32).  Units are stored in exactly the order the kernel
+// consumes them, so the kernel's LDS ring is a sliding window over a flat array
+// filled by global_load_lds, and lane l always reads unit + 16 l.
+//
+// Order: layer -> tile group (NG output tiles computed together) -> segment
+// (first the k-units fed by an encoder, then the k-units fed by the previous
+// layer) -> k-unit -> tile in group.  Every segment is padded to whole PIECES of
+// 8 units; the ring is filled and handed over piece by piece.
 #pragma once
 #include "common.hpp"
 
 namespace nerfx {
 
 constexpr int UNIT_BYTES = 1024;
-constexpr int CHUNK_UNITS = 16;                 // ring granularity: 16 KiB
-constexpr int RING_SLOTS = 8;                   // 128 KiB of LDS
-constexpr int RING_AHEAD = 6;                   // chunks in flight ahead of the consumer
+constexpr int PIECE_UNITS = 8;                  // ring granularity: 8 KiB
+constexpr int RING_PIECES = 16;                 // 128 KiB of LDS
+constexpr int RING_AHEAD = 12;                  // pieces in flight ahead of the consumer
+constexpr int SYNC_PIECES = RING_PIECES - RING_AHEAD;   // most pieces one hand-over may cover
+constexpr int ENC_BLOCK = 4;                    // encoder k-units come in multiples of this
 constexpr int MAX_LAYERS = 20;                  // 2*hd trunk + features + rgb.0 + rgb.2, depth <= 16
 constexpr int BIAS_STRIDE = 256;                // floats of const block per layer
 constexpr int MAX_TABLE = 1024;                 // floats per encoder table
 
-// slots (input features) per k-unit and units per 32-feature activation tile
+// slots (input features) per k-unit and k-units per 32-feature activation tile
 __host__ __device__ constexpr int slots_per_unit(int prec) { return prec == NERFX_PREC_BF16 ? 16 : 8; }
 __host__ __device__ constexpr int units_per_tile(int prec) { return prec == NERFX_PREC_BF16 ? 2 : 4; }
 
@@ -38,9 +44,11 @@ __host__ __device__ inline int enc_slot_col(int kind, int n, int slot) {
     const int c = slot - 2 * P;
     return (kind == NERFX_ENC_POSITIONAL && c < 3) ? c : -1;
 }
+// k-units an encoder occupies (padded with zero weights to a multiple of ENC_BLOCK).
 __host__ __device__ inline int enc_units(int kind, int n, int prec) {
     const int slots = (kind == NERFX_ENC_POSITIONAL ? 6 * n + 3 : 2 * n);
-    return (slots + slots_per_unit(prec) - 1) / slots_per_unit(prec);
+    const int units = (slots + slots_per_unit(prec) - 1) / slots_per_unit(prec);
+    return (units + ENC_BLOCK - 1) / ENC_BLOCK * ENC_BLOCK;
 }
 // Encoder slot supplied by lane half h as element e of k-unit u.
 __host__ __device__ inline int enc_unit_slot(int prec, int u, int h, int e) {
@@ -55,15 +63,17 @@ __host__ __device__ inline int chain_unit_feature(int prec, int u, int h, int e)
     return 8 * u + 4 * h + e;
 }
 
-// Output tiles a layer computes at a time (its k-block is this many units): bounded by
-// the accumulator registers that fit beside the input and output fragments.
+// Output tiles a layer computes at a time: bounded by the accumulator registers that
+// fit beside the input and output fragments.
 __host__ __device__ constexpr int group_tiles(int prec, int n_tiles) {
     const int cap = prec == NERFX_PREC_BF16 ? 2 : 4;
     return n_tiles < cap ? n_tiles : cap;
 }
+__host__ __device__ constexpr int pad_to_piece(int units) {
+    return (units + PIECE_UNITS - 1) / PIECE_UNITS * PIECE_UNITS;
+}
 
-// One Linear layer as the kernels see it.  Units are ordered
-// [tile group][k-unit][tile in group].
+// One Linear layer as the kernels see it.
 struct LayerPlan {
     int n_tiles;        // output tiles of 32 rows
     int out_dim;        // true rows
@@ -72,26 +82,27 @@ struct LayerPlan {
     int chain_tiles;    // 32-feature input tiles fed by the previous layer (0 for the first)
     int chain_dim;      // true chained inputs
     int in_dim;         // leading dimension of the reference weight (enc_cols + chain_dim)
+    int group;          // NG
+    int enc_seg;        // units of one group's encoder segment (padded to pieces)
+    int chain_seg;      // units of one group's chained segment (padded to pieces)
     int64_t unit0;      // first unit of this layer in the stream
 };
 
 struct ModelPlan {
     nerfx_model_desc_t desc;
     int prec;
-    int wt;             // hidden tiles: ceil(width / 32)
-    int rt;             // rgb.0 output tiles: ceil(width / 2 / 32)
+    int wt;             // hidden tiles (power of two): 32 * wt >= width
+    int rt;             // rgb.0 output tiles
     int hd;             // layers per trunk half
     int n_layers;       // 2*hd + 3
     LayerPlan layer[MAX_LAYERS];
-    int64_t trunk_units;   // stream units up to and including the last trunk layer (chunk padded)
-    int64_t total_units;   // whole stream (chunk padded)
+    int64_t trunk_units;   // stream units up to and including the last trunk layer
+    int64_t total_units;   // whole stream
     // const block (floats): [layer biases | sigma w | sigma b | table x | table d]
     int sigw_off, sigb_off, tabx_off, tabd_off, const_floats;
 };
 
-inline int units_of(const LayerPlan& L, int prec) {
-    return (L.enc_units + L.chain_tiles * units_per_tile(prec)) * L.n_tiles;
-}
+__host__ __device__ inline int units_of(const LayerPlan& L) { return (L.n_tiles / L.group) * (L.enc_seg + L.chain_seg); }
 
 // Fills `p` from a model description; returns 0 or an error code.
 int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p);

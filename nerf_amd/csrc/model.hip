@@ -27,7 +27,6 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
     const int ex_cols = enc_width(d.enc_x_kind, d.enc_x_n), ed_cols = enc_width(d.enc_d_kind, d.enc_d_n);
     const int ex_units = enc_units(d.enc_x_kind, d.enc_x_n, prec), ed_units = enc_units(d.enc_d_kind, d.enc_d_n, prec);
     int64_t unit = 0;
-    auto pad = [](int64_t u) { return (u + CHUNK_UNITS - 1) / CHUNK_UNITS * CHUNK_UNITS; };
     for (int li = 0; li < p.n_layers; ++li) {
         LayerPlan& L = p.layer[li];
         L = LayerPlan{};
@@ -35,7 +34,6 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
         const bool with_x = li == 0 || (li == p.hd && d.resid);
         if (with_x) { L.enc_units = ex_units; L.enc_kind = d.enc_x_kind; L.enc_n = d.enc_x_n; L.enc_cols = ex_cols; }
         if (li == 0) { L.chain_tiles = 0; L.chain_dim = 0; }
-        if (li == 2 * p.hd) unit = pad(unit);                       // features starts a chunk
         if (li == 2 * p.hd + 1) {                                   // rgb.0
             L.n_tiles = p.rt; L.out_dim = d.width / 2;
             L.enc_units = ed_units; L.enc_kind = d.enc_d_kind; L.enc_n = d.enc_d_n; L.enc_cols = ed_cols;
@@ -44,11 +42,14 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
             L.n_tiles = 1; L.out_dim = 3; L.chain_tiles = p.rt; L.chain_dim = d.width / 2;
         }
         L.in_dim = L.enc_cols + L.chain_dim;
+        L.group = group_tiles(prec, L.n_tiles);
+        L.enc_seg = L.enc_units / ENC_BLOCK * pad_to_piece(ENC_BLOCK * L.group);   // block-wise padding
+        L.chain_seg = pad_to_piece(L.chain_tiles * units_per_tile(prec) * L.group);
         L.unit0 = unit;
-        unit += units_of(L, prec);
-        if (li == 2 * p.hd - 1) p.trunk_units = pad(unit);
+        unit += units_of(L);
+        if (li == 2 * p.hd - 1) p.trunk_units = unit;
     }
-    p.total_units = pad(unit);
+    p.total_units = unit;
     p.sigw_off = p.n_layers * BIAS_STRIDE;
     p.sigb_off = p.sigw_off + BIAS_STRIDE;
     p.tabx_off = p.sigb_off + 4;
@@ -57,31 +58,45 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
     return 0;
 }
 
-// One thread per packed 16-byte lane slice of one layer.
+// One thread per packed 16-byte lane slice of one layer (padding units included).
 template <int PREC>
 __global__ __launch_bounds__(256) void pack_layer_kernel(const float* __restrict__ W, LayerPlan L,
                                                          void* __restrict__ stream) {
     constexpr int EPL = PREC == NERFX_PREC_BF16 ? 8 : 4;          // elements per lane per unit
-    const int k_units = L.enc_units + L.chain_tiles * units_per_tile(PREC);
-    const int64_t n_slices = (int64_t)k_units * L.n_tiles * 64;
+    const int group_units = L.enc_seg + L.chain_seg;
+    const int64_t n_slices = (int64_t)units_of(L) * 64;
     for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < n_slices; s += (int64_t)gridDim.x * 256) {
         const int lane = (int)(s & 63);
-        const int64_t unit = s >> 6;                               // = (grp * k_units + ku) * ng + t
-        const int ng = group_tiles(PREC, L.n_tiles);
-        const int t = (int)(unit % ng), gk = (int)(unit / ng);
-        const int grp = gk / k_units, ku = gk - grp * k_units, nt = grp * ng + t;
-        const int row = 32 * nt + (lane & 31), h = lane >> 5;
+        const int64_t unit = s >> 6;
+        const int grp = (int)(unit / group_units);
+        int in_group = (int)(unit - (int64_t)grp * group_units);
+        const bool enc = in_group < L.enc_seg;
+        int ku, t;                                                  // [k-unit][tile in group]
+        bool live;
+        if (enc) {                                                  // ENC_BLOCK k-units per padded block
+            const int block_units = pad_to_piece(ENC_BLOCK * L.group);
+            const int eb = in_group / block_units, within = in_group - eb * block_units;
+            ku = eb * ENC_BLOCK + within / L.group;
+            t = within % L.group;
+            live = within < ENC_BLOCK * L.group;
+        } else {
+            in_group -= L.enc_seg;
+            ku = in_group / L.group;
+            t = in_group - ku * L.group;
+            live = ku < L.chain_tiles * units_per_tile(PREC);
+        }
+        const int row = 32 * (grp * L.group + t) + (lane & 31), h = lane >> 5;
         float v[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             int col;
-            if (ku < L.enc_units) {
+            if (enc) {
                 col = enc_slot_col(L.enc_kind, L.enc_n, enc_unit_slot(PREC, ku, h, e));
             } else {
-                const int f = chain_unit_feature(PREC, ku - L.enc_units, h, e);
+                const int f = chain_unit_feature(PREC, ku, h, e);
                 col = f < L.chain_dim ? L.enc_cols + f : -1;
             }
-            v[e] = (row < L.out_dim && col >= 0) ? W[(int64_t)row * L.in_dim + col] : 0.0f;
+            v[e] = (live && row < L.out_dim && col >= 0) ? W[(int64_t)row * L.in_dim + col] : 0.0f;
         }
         char* dst = (char*)stream + (L.unit0 + unit) * UNIT_BYTES + lane * 16;
         if (PREC == NERFX_PREC_BF16) {
@@ -116,10 +131,9 @@ static int pack_all(nerfx_model* m, const float* const* tensors, hipStream_t str
     for (int i = 0; i < m->n_tensors; ++i) NERFX_REQUIRE(tensors[i] != nullptr, "tensor %d is NULL", i);
     for (int prec = 0; prec < 2; ++prec) {
         const ModelPlan& p = m->plan[prec];
-        NERFX_HIP(hipMemsetAsync(m->stream_dev[prec], 0, (size_t)p.total_units * UNIT_BYTES, stream));
         for (int li = 0; li < p.n_layers; ++li) {
             const LayerPlan& L = p.layer[li];
-            const int64_t slices = (int64_t)units_of(L, prec) * 64;
+            const int64_t slices = (int64_t)units_of(L) * 64;
             const int grid = (int)std::min<int64_t>((slices + 255) / 256, 4096);
             const float* W = tensors[tensor_index(p, li, false)];
             if (prec == NERFX_PREC_BF16)

@@ -16,11 +16,13 @@ from oracle import nerf_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture()
 def ops():
     import nerf_amd.ops as ops_
     assert torch.cuda.is_available(), "GPU tests need a ROCm device"
-    return ops_
+    ops_.set_precision(None)
+    yield ops_
+    ops_.set_precision(None)          # a failed test must not leak its precision override
 
 
 def dev(x):
