@@ -174,6 +174,12 @@ int nerfx_render_fwd(const nerfx_model_t* coarse, const nerfx_model_t* fine, int
                      void* workspace, int64_t workspace_bytes,
                      float* t, float* weights, float* depth_map, float* rgb_map, void* stream);
 
+/* ---- diagnostics --------------------------------------------------------------------
+ * No counterpart in the reference.  In a library built with -DNERFX_STAMPS the MLP kernels
+ * add per-phase cycle counts (6 x uint64: prologue, ring hand-over, MFMA runs, epilogue,
+ * heads, encode) into `device_buffer`; NULL switches it off.  A regular build ignores it. */
+void nerfx_debug_set_stamps(unsigned long long* device_buffer);
+
 #ifdef __cplusplus
 }
 #endif

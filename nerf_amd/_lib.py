@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerfx.so")
+LIB_PATH = os.environ.get("NERFX_LIB", os.path.join(_HERE, "libnerfx.so"))   # override: diagnostic builds
 
 ENC_POSITIONAL, ENC_FOURIER = 0, 1
 ACT_RELU, ACT_LEAKY_RELU, ACT_SILU = 0, 1, 2
@@ -44,6 +44,7 @@ SIGNATURES = {
     "nerfx_segment_lengths": (_i, [_p, _p, _l, _i, _p, _p]),
     "nerfx_pdf_sample": (_i, [_p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p]),
     "nerfx_searchsorted_right": (_i, [_p, _p, _l, _i, _i, _p, _p]),
+    "nerfx_debug_set_stamps": (None, [_p]),
     "nerfx_render_workspace_bytes": (_l, [_l, _i, _i]),
     "nerfx_render_fwd": (_i, [_p, _p, _i, _p, _p, _l, _f, _f, _i, _i, _p, _p, _p, _l,
                               _p, _p, _p, _p, _p]),

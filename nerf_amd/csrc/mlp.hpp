@@ -18,9 +18,20 @@ namespace nerfx {
 
 constexpr int UNIT_BYTES = 1024;
 constexpr int PIECE_UNITS = 8;                  // ring granularity: 8 KiB
-constexpr int RING_PIECES = 16;                 // 128 KiB of LDS
-constexpr int RING_AHEAD = 12;                  // pieces in flight ahead of the consumer
-constexpr int SYNC_PIECES = RING_PIECES - RING_AHEAD;   // most pieces one hand-over may cover
+// Ring geometry of one kernel configuration: WAVES wavefronts per workgroup share a ring of
+// PIECES pieces, AHEAD of which are in flight ahead of the consumer; one hand-over covers
+// at most SYNC = PIECES - AHEAD pieces.
+template <int WAVES_, int PIECES_, int AHEAD_, int BLOCKS_PER_CU_>
+struct RingGeometry {
+    static constexpr int WAVES = WAVES_, PIECES = PIECES_, AHEAD = AHEAD_, SYNC = PIECES_ - AHEAD_;
+    static constexpr int BLOCKS_PER_CU = BLOCKS_PER_CU_;
+};
+// bf16: one 8-wave workgroup per CU (two waves per SIMD, 256 registers each); the ring leaves
+// room for the per-wave encoding stash.  fp32: one 4-wave workgroup per CU (512 registers).
+using RingBf16 = RingGeometry<8, 12, 8, 1>;
+using RingFp32 = RingGeometry<4, 16, 12, 1>;
+// bf16 kernels keep each wave's positional-encoding B operands (ENC_BLOCK k-units) in LDS.
+constexpr int STASH_BYTES_PER_WAVE = 4 * 1024;
 constexpr int ENC_BLOCK = 4;                    // encoder k-units come in multiples of this
 constexpr int MAX_LAYERS = 20;                  // 2*hd trunk + features + rgb.0 + rgb.2, depth <= 16
 constexpr int BIAS_STRIDE = 256;                // floats of const block per layer

@@ -2,13 +2,19 @@
 #include "mlp_fwd_impl.hpp"
 
 namespace nerfx {
-int launch_mlp_bf16(int activ, int wt, const MlpArgs& a, size_t lds, hipStream_t s);
-int launch_mlp_fp32(int activ, int wt, const MlpArgs& a, size_t lds, hipStream_t s);
-int launch_mlp_bf16_bigenc(int activ, int wt, const MlpArgs& a, size_t lds, hipStream_t s);
-int launch_mlp_fp32_bigenc(int activ, int wt, const MlpArgs& a, size_t lds, hipStream_t s);
+int launch_mlp_bf16(int activ, int wt, const MlpArgs& a, hipStream_t s);
+int launch_mlp_fp32(int activ, int wt, const MlpArgs& a, hipStream_t s);
+int launch_mlp_bf16_bigenc(int activ, int wt, const MlpArgs& a, hipStream_t s);
+int launch_mlp_fp32_bigenc(int activ, int wt, const MlpArgs& a, hipStream_t s);
+int launch_mlp_bf16_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
+int launch_mlp_fp32_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
 }  // namespace nerfx
 
 using namespace nerfx;
+
+// Diagnostic hook (only meaningful in -DNERFX_STAMPS builds): device buffer of 6 cycle buckets.
+static unsigned long long* g_stamps = nullptr;
+extern "C" void nerfx_debug_set_stamps(unsigned long long* device_buffer) { g_stamps = device_buffer; }
 
 static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0, const float* p1, const float* t,
                       int64_t n_points, int n_samples, float* sigma, float* rgb, void* stream) {
@@ -18,7 +24,7 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
     if (n_points == 0) return 0;
     NERFX_REQUIRE(p0 && p1 && sigma, "NULL input or output");
     const ModelPlan& p = model->plan[precision];
-    const int waves = precision == NERFX_PREC_BF16 ? 8 : 4;
+    const int waves = precision == NERFX_PREC_BF16 ? RingBf16::WAVES : RingFp32::WAVES;
     MlpArgs a{};
     a.stream = (const char*)model->stream_dev[precision];
     a.consts = model->const_dev;
@@ -32,13 +38,14 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
     a.ed_kind = p.desc.enc_d_kind; a.ed_n = p.desc.enc_d_n; a.ed_units = p.layer[2 * p.hd + 1].enc_units;
     a.sigw_off = p.sigw_off; a.sigb_off = p.sigb_off; a.tabx_off = p.tabx_off; a.tabd_off = p.tabd_off;
     a.const_floats = p.const_floats;
-    const size_t lds = (size_t)p.const_floats * sizeof(float) + (size_t)RING_PIECES * PIECE_UNITS * UNIT_BYTES;
-    NERFX_REQUIRE(lds <= 160 * 1024, "model needs %zu bytes of LDS (> 160 KiB)", lds);
+    a.stamps = g_stamps;
     // encoders that fit the kernels' register cache take the fast instantiations
     const bool big = a.ex_units > ENC_BLOCK || a.ed_units > ENC_BLOCK;
+    if (!big && p.wt == 8 && p.desc.resid && (p.hd == 2 || p.hd == 4))          // compile-time depth
+        return (precision == NERFX_PREC_BF16 ? launch_mlp_bf16_fixed : launch_mlp_fp32_fixed)(p.desc.activ, p.hd, a, (hipStream_t)stream);
     auto launch = precision == NERFX_PREC_BF16 ? (big ? launch_mlp_bf16_bigenc : launch_mlp_bf16)
                                                : (big ? launch_mlp_fp32_bigenc : launch_mlp_fp32);
-    return launch(p.desc.activ, p.wt, a, lds, (hipStream_t)stream);
+    return launch(p.desc.activ, p.wt, a, (hipStream_t)stream);
 }
 
 extern "C" int nerfx_mlp_fwd_points(const nerfx_model_t* model, int precision, const float* x, const float* d,

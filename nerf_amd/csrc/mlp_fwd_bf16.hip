@@ -2,7 +2,7 @@
 // (one translation unit per precision and encoder class so that they compile in parallel).
 #include "mlp_fwd_impl.hpp"
 namespace nerfx {
-int launch_mlp_bf16(int activ, int wt, const MlpArgs& a, size_t lds, hipStream_t s) {
-    return launch_activation<NERFX_PREC_BF16, 8, false>(activ, wt, a, lds, s);
+int launch_mlp_bf16(int activ, int wt, const MlpArgs& a, hipStream_t s) {
+    return launch_activation<NERFX_PREC_BF16, RingBf16, false>(activ, wt, a, s);
 }
 }  // namespace nerfx

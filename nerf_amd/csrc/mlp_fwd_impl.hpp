@@ -50,14 +50,39 @@ struct MlpArgs {
     int hd, resid;
     int ex_kind, ex_n, ex_units, ed_kind, ed_n, ed_units;
     int sigw_off, sigb_off, tabx_off, tabd_off, const_floats;
+    unsigned long long* stamps;  // diagnostic builds: 6 cycle buckets, else NULL
 };
 
+// ---- optional in-kernel cycle accounting (diagnostic builds only: -DNERFX_STAMPS) -------
+// Bucket b accumulates the s_memtime cycles a wave spends between mark(b') and mark(b).
+struct Stamps {
+#ifdef NERFX_STAMPS
+    unsigned long long last, sum[6];
+    __device__ __forceinline__ void start() { last = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 6; ++i) sum[i] = 0; }
+    __device__ __forceinline__ void mark(int b) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        sum[b] += now - last; last = now;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void flush(unsigned long long* out, int lane) {
+        if (lane == 0 && out) for (int i = 0; i < 6; ++i) atomicAdd(out + i, sum[i]);
+    }
+#else
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(unsigned long long*, int) {}
+#endif
+};
+enum { ST_PROLOGUE = 0, ST_ACQUIRE = 1, ST_RUN = 2, ST_EPILOGUE = 3, ST_HEADS = 4, ST_ENCODE = 5 };
+
 // ---- LDS weight ring ---------------------------------------------------------------
-template <int WAVES>
+template <class RG>
 struct WeightRing {
+    static constexpr int WAVES = RG::WAVES, RING_PIECES = RG::PIECES, RING_AHEAD = RG::AHEAD, SYNC_PIECES = RG::SYNC;
     static constexpr int LPW = PIECE_UNITS / WAVES;         // global_load_lds per wave per piece
     static_assert(PIECE_UNITS % WAVES == 0, "a piece must split evenly over the waves");
-    const char* src;             // this lane's source: stream + (wave * LPW) KiB + 16 lane
+    const char* src;             // stream base (wave-uniform; lanes add their own 32-bit offset)
     lds_bytes_t lds;             // ring base
     uint32_t n_pieces, issue_piece, issue_slot;
     uint32_t piece;              // consumer position: ring slot of the current segment's first piece
@@ -66,16 +91,18 @@ struct WeightRing {
     __device__ __forceinline__ void issue() {
 #pragma unroll
         for (int k = 0; k < LPW; ++k) {
-            const char* g = src + ((size_t)issue_piece * PIECE_UNITS + k) * UNIT_BYTES;
+            // uniform 64-bit base + 32-bit lane offset: the lane part is cheap to rebuild, so nothing
+            // 64-bit and per-lane has to stay live between hand-overs
+            const char* g = src + ((size_t)issue_piece * PIECE_UNITS + wave * LPW + k) * UNIT_BYTES + (uint32_t)(lane * 16);
             lds_bytes_t l = lds + (issue_slot * PIECE_UNITS + wave * LPW + k) * UNIT_BYTES;
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)g,
                                              (void __attribute__((address_space(3)))*)l, 16, 0, 0);
         }
         issue_piece = issue_piece + 1 == n_pieces ? 0 : issue_piece + 1;
-        issue_slot = (issue_slot + 1) & (RING_PIECES - 1);
+        issue_slot = issue_slot + 1 == RING_PIECES ? 0 : issue_slot + 1;
     }
     __device__ __forceinline__ void init(const char* s, lds_bytes_t l, uint32_t np, int w, int ln) {
-        src = s + (size_t)(w * LPW) * UNIT_BYTES + ln * 16;
+        src = s;
         lds = l; n_pieces = np; wave = w; lane = ln;
         issue_piece = 0; issue_slot = 0; piece = 0;
 #pragma unroll
@@ -95,10 +122,11 @@ struct WeightRing {
         for (int i = 0; i < N; ++i) issue();
     }
     template <int N>
-    __device__ __forceinline__ void release() { piece = (piece + N) & (RING_PIECES - 1); }
+    __device__ __forceinline__ void release() { piece = piece + N >= RING_PIECES ? piece + N - RING_PIECES : piece + N; }
     // Address of unit `rel` (compile-time) of the segment that starts at `piece`.
     __device__ __forceinline__ lds_bytes_t unit_ptr(int rel) const {
-        const uint32_t slot = (piece + rel / PIECE_UNITS) & (RING_PIECES - 1);
+        uint32_t slot = piece + rel / PIECE_UNITS;
+        slot = slot >= RING_PIECES ? slot - RING_PIECES : slot;
         return lds + slot * (PIECE_UNITS * UNIT_BYTES) + (rel % PIECE_UNITS) * UNIT_BYTES + lane * 16;
     }
 };
@@ -129,8 +157,11 @@ template <> struct Prec<NERFX_PREC_BF16> {
         const s16x8 v = __builtin_bit_cast(s16x8, f);
         return __builtin_bit_cast(Frag, __builtin_elementwise_max(v, s16x8(0)));
     }
-    static __device__ __forceinline__ void mma(f32x16& acc, lds_bytes_t unit, const Frag& b) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(NERFX_LDS_VEC(bf16x8, unit), b, acc, 0, 0, 0);
+    using AFrag = bf16x8;                                   // weights of one unit for this lane
+    static constexpr int MFMA_PER_UNIT = 1;
+    static __device__ __forceinline__ AFrag load_a(lds_bytes_t unit) { return NERFX_LDS_VEC(bf16x8, unit); }
+    static __device__ __forceinline__ void mma(f32x16& acc, const AFrag& a, const Frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
     static __device__ __forceinline__ void sincos_pair(float angle, float& s, float& c) {
         float r = angle * 0.15915494309189535f;             // revolutions
@@ -152,8 +183,10 @@ template <> struct Prec<NERFX_PREC_FP32> {
     }
     static constexpr bool PACKED_RELU = false;
     static __device__ __forceinline__ Frag relu(const Frag& f) { return f; }
-    static __device__ __forceinline__ void mma(f32x16& acc, lds_bytes_t unit, const Frag& b) {
-        const f32x4 a = NERFX_LDS_VEC(f32x4, unit);
+    using AFrag = f32x4;
+    static constexpr int MFMA_PER_UNIT = 4;
+    static __device__ __forceinline__ AFrag load_a(lds_bytes_t unit) { return NERFX_LDS_VEC(f32x4, unit); }
+    static __device__ __forceinline__ void mma(f32x16& acc, const AFrag& a, const Frag& b) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
     }
@@ -214,6 +247,48 @@ __device__ __forceinline__ float activate(float x) {
     return x;                                                // ACT < 0: plain Linear
 }
 
+#include "mlp_runs_bf16.inc"
+
+// One acquired run of N units: unit i multiplies B operand b(i) into acc[i % NG].  The A
+// operands are read LOOKAHEAD units ahead of the MFMA that consumes them; the interleave is
+// pinned with sched_group_barrier (ds_read = 0x100, MFMA = 0x8) because hipcc otherwise
+// serialises read -> wait -> MFMA on one register set when registers are tight.
+constexpr int LOOKAHEAD = 4;
+template <int PREC, class RG, int NG, int N, class BSource>
+__device__ __forceinline__ void run_units(const WeightRing<RG>& ring, f32x16 (&acc)[NG], BSource b) {
+    using P = Prec<PREC>;
+    if constexpr (PREC == NERFX_PREC_BF16 && NG == 2 && (N == 8 || N == 16 || N == 32)) {
+        // hand-scheduled block: counted lgkmcnt waits (see mlp_runs_bf16.inc)
+        uint32_t p[N / PIECE_UNITS];
+#pragma unroll
+        for (int k = 0; k < N / PIECE_UNITS; ++k) p[k] = (uint32_t)(uintptr_t)ring.unit_ptr(k * PIECE_UNITS);
+        if constexpr (N == 8) run8_bf16_ng2(acc[0], acc[1], p[0], b(0), b(1), b(2), b(3));
+        if constexpr (N == 16) run16_bf16_ng2(acc[0], acc[1], p[0], p[1], b(0), b(1), b(2), b(3), b(4), b(5), b(6), b(7));
+        if constexpr (N == 32)
+            run32_bf16_ng2(acc[0], acc[1], p[0], p[1], p[2], p[3], b(0), b(1), b(2), b(3), b(4), b(5), b(6), b(7),
+                           b(8), b(9), b(10), b(11), b(12), b(13), b(14), b(15));
+        return;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    typename P::AFrag a[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = P::load_a(ring.unit_ptr(i));
+#pragma unroll
+    for (int i = 0; i < N; ++i) P::mma(acc[i % NG], a[i], b(i / NG));
+    constexpr int D = LOOKAHEAD < N ? LOOKAHEAD : N;
+    __builtin_amdgcn_sched_group_barrier(0x100, D, 0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, P::MFMA_PER_UNIT, 0);
+        if (i + D < N) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Whether a kernel configuration keeps the positional encoding of x in the LDS stash.
+template <int PREC, int WT, bool BIGENC>
+constexpr bool uses_stash() { return PREC == NERFX_PREC_BF16 && !BIGENC && WT >= 2; }
+
 // ---- one Linear layer -------------------------------------------------------------------
 // out = act(W . [encoder units | chained input] + b), computed NG output tiles at a time so
 // that only NG accumulator tiles are live beside the input and output fragments.
@@ -222,14 +297,15 @@ __device__ __forceinline__ float activate(float x) {
 //   with_enc: this layer's stream carries an encoder segment (wave-uniform)
 //   SIGMA: also accumulate the density head's dot product on the fp32 activations
 //   raw  : if non-null (NT == 1 only) receives the fp32 accumulator tile instead of hout
-template <int PREC, int WAVES, int ACT, bool BIGENC, int NT, int CT, bool SIGMA, int HN_IN, int HN_OUT>
-__device__ __forceinline__ float linear(WeightRing<WAVES>& ring, lds_floats_t bias, int h,
+template <int PREC, class RG, int ACT, bool BIGENC, int NT, int CT, bool SIGMA, bool STASH = false, int HN_IN = 0, int HN_OUT = 0>
+__device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias, int h,
                                         const typename Prec<PREC>::Frag (&hin)[HN_IN],
                                         typename Prec<PREC>::Frag (&hout)[HN_OUT],
                                         bool with_enc, const Encoding<PREC>& enc, lds_floats_t sigw,
-                                        f32x16* raw = nullptr) {
+                                        Stamps& st, f32x16* raw = nullptr, uint32_t stash = 0) {
     using P = Prec<PREC>;
     constexpr int NG = group_tiles(PREC, NT);
+    constexpr int SYNC_PIECES = RG::SYNC;
     constexpr int KB_PER_PIECE = PIECE_UNITS / NG;              // k-blocks (NG units each) per piece
     constexpr int CHAIN_KU = CT * P::UPT;
     constexpr int CHAIN_PIECES = pad_to_piece(CHAIN_KU * NG) / PIECE_UNITS;
@@ -251,42 +327,54 @@ __device__ __forceinline__ float linear(WeightRing<WAVES>& ring, lds_floats_t bi
         }
         if (with_enc) {
             if (!BIGENC) {                                         // register-resident encoding
+                st.mark(ST_EPILOGUE);
                 ring.template acquire<ENC_PIECES>();
-#pragma unroll
-                for (int u = 0; u < ENC_BLOCK; ++u)
-#pragma unroll
-                    for (int t = 0; t < NG; ++t) P::mma(acc[t], ring.unit_ptr(u * NG + t), enc.cached[u]);
+                st.mark(ST_ACQUIRE);
+                if constexpr (STASH) {                             // B operands from the wave's LDS stash
+                    static_assert(PREC == NERFX_PREC_BF16 && NG == 2, "stash blocks exist for bf16, two tiles");
+                    // `stash` is the wave-uniform byte offset of this wave's stash; the lane part is
+                    // re-added here so that no per-lane address has to stay live across layers
+                    run8_bf16_ng2_stash(acc[0], acc[1], (uint32_t)(uintptr_t)ring.unit_ptr(0), stash,
+                                        (uint32_t)ring.lane * 16u);
+                } else {
+                    run_units<PREC, RG, NG, ENC_BLOCK * NG>(ring, acc, [&](int u) { return enc.cached[u]; });
+                }
+                st.mark(ST_RUN);
                 ring.template release<ENC_PIECES>();
             } else {
                 for (int u0 = 0; u0 < enc.units; u0 += ENC_BLOCK) {
+                    typename P::Frag eb[ENC_BLOCK];
+#pragma unroll
+                    for (int u = 0; u < ENC_BLOCK; ++u) eb[u] = enc.eval(u0 + u);
                     ring.template acquire<ENC_PIECES>();
-#pragma unroll
-                    for (int u = 0; u < ENC_BLOCK; ++u) {
-                        const typename P::Frag b = enc.eval(u0 + u);
-#pragma unroll
-                        for (int t = 0; t < NG; ++t) P::mma(acc[t], ring.unit_ptr(u * NG + t), b);
-                    }
+                    run_units<PREC, RG, NG, ENC_BLOCK * NG>(ring, acc, [&](int u) { return eb[u]; });
                     ring.template release<ENC_PIECES>();
                 }
             }
         }
         // chained input, handed over SYNC_PIECES pieces at a time
+        if constexpr (CHAIN_KU > 0)
 #pragma unroll
         for (int p0 = 0; p0 < CHAIN_PIECES; p0 += SYNC_PIECES) {
-            constexpr int dummy = 0; (void)dummy;
-            if (CHAIN_PIECES - p0 >= SYNC_PIECES) ring.template acquire<SYNC_PIECES>();
-            else ring.template acquire<(CHAIN_PIECES % SYNC_PIECES) ? (CHAIN_PIECES % SYNC_PIECES) : SYNC_PIECES>();
-#pragma unroll
-            for (int kb = 0; kb < SYNC_PIECES * KB_PER_PIECE; ++kb) {
-                const int ku = p0 * KB_PER_PIECE + kb;
-                if (ku < CHAIN_KU) {
-#pragma unroll
-                    for (int t = 0; t < NG; ++t) P::mma(acc[t], ring.unit_ptr(kb * NG + t), hin[ku]);
-                }
-                if ((kb & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            constexpr int TAIL = CHAIN_PIECES % SYNC_PIECES ? CHAIN_PIECES % SYNC_PIECES : SYNC_PIECES;
+            const int ku0 = p0 * KB_PER_PIECE;
+            if (CHAIN_PIECES - p0 >= SYNC_PIECES) {
+                constexpr int KU = SYNC_PIECES * KB_PER_PIECE;
+                st.mark(ST_EPILOGUE);
+                ring.template acquire<SYNC_PIECES>();
+                st.mark(ST_ACQUIRE);
+                run_units<PREC, RG, NG, KU * NG>(ring, acc, [&](int k) { return hin[ku0 + k]; });
+                st.mark(ST_RUN);
+                ring.template release<SYNC_PIECES>();
+            } else {
+                constexpr int KU = CHAIN_KU - (CHAIN_PIECES - TAIL) * KB_PER_PIECE;   // k-units in the tail run
+                st.mark(ST_EPILOGUE);
+                ring.template acquire<TAIL>();
+                st.mark(ST_ACQUIRE);
+                run_units<PREC, RG, NG, (KU > 0 ? KU : 1) * NG>(ring, acc, [&](int k) { return hin[ku0 + k]; });
+                st.mark(ST_RUN);
+                ring.template release<TAIL>();
             }
-            if (CHAIN_PIECES - p0 >= SYNC_PIECES) ring.template release<SYNC_PIECES>();
-            else ring.template release<(CHAIN_PIECES % SYNC_PIECES) ? (CHAIN_PIECES % SYNC_PIECES) : SYNC_PIECES>();
         }
         // epilogue: activation, density dot, conversion to the next layer's operands
         constexpr bool packed_relu = ACT == NERFX_ACT_RELU && P::PACKED_RELU && !SIGMA;
@@ -321,8 +409,13 @@ __device__ __forceinline__ float linear(WeightRing<WAVES>& ring, lds_floats_t bi
     return dot;
 }
 
-template <int PREC, int WT, int WAVES, int ACT, bool BIGENC>
-__global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
+// HD > 0 fixes the number of layers per trunk half at compile time (with the skip
+// connection on): the block body is then straight-line code, which hipcc allocates without
+// the loop-carried copies of the activation fragments that the runtime-depth form (HD = 0)
+// needs and spills.
+template <int PREC, int WT, class RG, int ACT, bool BIGENC, int HD>
+__global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) void mlp_fwd_kernel(const MlpArgs a) {
+    constexpr int WAVES = RG::WAVES;
     using P = Prec<PREC>;
     using Frag = typename P::Frag;
     constexpr int RT = WT > 1 ? WT / 2 : 1;
@@ -332,15 +425,23 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
 
-    WeightRing<WAVES> ring;
-    ring.init(a.stream, (lds_bytes_t)smem + a.const_floats * (int)sizeof(float), a.n_pieces, wave, lane);
+    // LDS: [const block | per-wave encoding stash (bf16 kernels) | weight ring]
+    constexpr bool STASH = uses_stash<PREC, WT, BIGENC>();
+    const lds_bytes_t stash_base = (lds_bytes_t)smem + a.const_floats * (int)sizeof(float);
+    const lds_bytes_t my_stash = stash_base + wave * STASH_BYTES_PER_WAVE + lane * 16;
+    WeightRing<RG> ring;
+    ring.init(a.stream, stash_base + (STASH ? WAVES * STASH_BYTES_PER_WAVE : 0), a.n_pieces, wave, lane);
     for (int i = tid; i < a.const_floats; i += 64 * WAVES) cst[i] = a.consts[i];
     __syncthreads();
 
     const lds_floats_t sigw = cst + a.sigw_off;
     const bool colour = a.rgb != nullptr;
-    const int last = 2 * a.hd - 1;                                 // last trunk layer feeds the density head
+    const int hd = HD > 0 ? HD : a.hd;
+    const bool resid = HD > 0 ? true : a.resid != 0;
+    const int last = 2 * hd - 1;                                   // last trunk layer feeds the density head
 
+    Stamps st;
+    st.start();
     for (uint32_t blk = blockIdx.x; blk < a.n_blocks; blk += gridDim.x) {
         // ---- this lane's sample (both lane halves hold the same one) ----------------
         const uint32_t m = blk * (32 * WAVES) + wave * 32 + (lane & 31);
@@ -362,26 +463,50 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
         const float probe = (px + py + pz) + (colour ? (dx + dy + dz) : 0.0f);
         const bool poisoned = !(fabsf(probe) <= 3.0e38f);
 
+        st.mark(ST_PROLOGUE);
+        // phi_x is consumed twice (layer 0 and the skip layer).  bf16 kernels park its B operands
+        // in the wave's LDS stash (the MFMA blocks read them from there); the others keep them
+        // in registers, (re)built right before each consuming layer.
         Encoding<PREC> enc;
         enc.template prepare<BIGENC>(a.ex_kind, a.ex_n, a.ex_units, cst + a.tabx_off, h, px, py, pz);
+        uint32_t stash = 0;
+        if constexpr (STASH) {
+#pragma unroll
+            for (int u = 0; u < ENC_BLOCK; ++u)
+                *reinterpret_cast<__attribute__((address_space(3))) Frag*>(my_stash + u * UNIT_BYTES) = enc.cached[u];
+            // same wave reads it back: LDS is in order per wave
+            stash = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(stash_base + wave * STASH_BYTES_PER_WAVE));
+        }
+        st.mark(ST_ENCODE);
         Frag A[HN], B[HN];                                        // ping-pong activation fragments
         float dot = 0.0f;
         // ---- fc_1 then fc_2; fc_2's first layer optionally sees [phi_x | h] (model.py:71-73).
         // Layer 0 writes A; the remaining 2 hd - 1 trunk layers alternate A -> B, B -> A, so the
         // last one always lands in B.
-        if (last == 0) dot = linear<PREC, WAVES, ACT, BIGENC, WT, 0, true>(ring, cst, h, A, B, true, enc, sigw);
-        else linear<PREC, WAVES, ACT, BIGENC, WT, 0, false>(ring, cst, h, B, A, true, enc, sigw);
+        if (last == 0) dot = linear<PREC, RG, ACT, BIGENC, WT, 0, true, STASH>(ring, cst, h, A, B, true, enc, sigw, st, nullptr, stash);
+        else linear<PREC, RG, ACT, BIGENC, WT, 0, false, STASH>(ring, cst, h, B, A, true, enc, sigw, st, nullptr, stash);
+        const int skip = resid ? hd : -1;                          // the layer that sees phi_x again
+        auto refresh = [&](int li) {                               // register-resident encodings only
+            if (!STASH && li == skip) {
+                st.mark(ST_EPILOGUE);
+                enc.template prepare<BIGENC>(a.ex_kind, a.ex_n, a.ex_units, cst + a.tabx_off, h, px, py, pz);
+                st.mark(ST_ENCODE);
+            }
+        };
         int li = 1;
+#pragma unroll
         for (; li + 1 <= last; li += 2) {
-            linear<PREC, WAVES, ACT, BIGENC, WT, WT, false>(ring, cst + li * BIAS_STRIDE, h, A, B,
-                                                    li == a.hd && a.resid, enc, sigw);
-            linear<PREC, WAVES, ACT, BIGENC, WT, WT, false>(ring, cst + (li + 1) * BIAS_STRIDE, h, B, A,
-                                                    li + 1 == a.hd && a.resid, enc, sigw);
+            refresh(li);
+            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH>(ring, cst + li * BIAS_STRIDE, h, A, B, li == skip, enc, sigw, st, nullptr, stash);
+            refresh(li + 1);
+            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH>(ring, cst + (li + 1) * BIAS_STRIDE, h, B, A, li + 1 == skip, enc, sigw, st, nullptr, stash);
         }
-        if (last > 0)
-            dot = linear<PREC, WAVES, ACT, BIGENC, WT, WT, true>(ring, cst + last * BIAS_STRIDE, h, A, B,
-                                                         last == a.hd && a.resid, enc, sigw);
+        if (last > 0) {
+            refresh(last);
+            dot = linear<PREC, RG, ACT, BIGENC, WT, WT, true, STASH>(ring, cst + last * BIAS_STRIDE, h, A, B, last == skip, enc, sigw, st, nullptr, stash);
+        }
         // ---- density head (model.py:75, activations.py:33-35) ------------------------------
+        st.mark(ST_EPILOGUE);
         {
             dot += __shfl_xor(dot, 32, 64);
             const float sx = (dot + cst[a.sigb_off]) - 1.0f;
@@ -389,18 +514,19 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
             if (poisoned) sg = __builtin_nanf("");
             if (valid && h == 0) a.sigma[m] = sg;
         }
+        st.mark(ST_HEADS);
         if (colour) {
             li = last + 1;
             // ---- features: Linear without activation (model.py:51, :76): B -> A ------------
-            linear<PREC, WAVES, -1, BIGENC, WT, WT, false>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw);
+            linear<PREC, RG, -1, BIGENC, WT, WT, false>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, st);
             ++li;
             // ---- rgb.0 on [phi_d | features] (model.py:53, :76): A -> B ---------------------
-            enc.template prepare<BIGENC>(a.ed_kind, a.ed_n, a.ed_units, cst + a.tabd_off, h, dx, dy, dz);
-            linear<PREC, WAVES, ACT, BIGENC, RT, WT, false>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw);
+            { st.mark(ST_EPILOGUE); enc.template prepare<BIGENC>(a.ed_kind, a.ed_n, a.ed_units, cst + a.tabd_off, h, dx, dy, dz); st.mark(ST_ENCODE); }
+            linear<PREC, RG, ACT, BIGENC, RT, WT, false>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw, st);
             ++li;
             // ---- rgb.2 + widened sigmoid (model.py:54, activations.py:18-20) ----------------
             f32x16 out;
-            linear<PREC, WAVES, -1, BIGENC, 1, RT, false>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, &out);
+            linear<PREC, RG, -1, BIGENC, 1, RT, false>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, st, &out);
             if (valid && h == 0) {
                 // rows 0..2 of the output tile sit in accumulator registers 0..2 of lane half 0
 #pragma unroll
@@ -411,13 +537,18 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
                 }
             }
         }
+        st.mark(ST_HEADS);
     }
+    st.flush(a.stamps, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int PREC, int WT, int WAVES, int ACT, bool BIGENC>
-static int launch_cfg(const MlpArgs& a, size_t lds_bytes, hipStream_t stream) {
-    auto kern = mlp_fwd_kernel<PREC, WT, WAVES, ACT, BIGENC>;
+template <int PREC, int WT, class RG, int ACT, bool BIGENC, int HD = 0>
+static int launch_cfg(const MlpArgs& a, hipStream_t stream) {
+    auto kern = mlp_fwd_kernel<PREC, WT, RG, ACT, BIGENC, HD>;
+    const size_t lds_bytes = (size_t)a.const_floats * sizeof(float) + (size_t)RG::PIECES * PIECE_UNITS * UNIT_BYTES +
+                             (uses_stash<PREC, WT, BIGENC>() ? (size_t)RG::WAVES * STASH_BYTES_PER_WAVE : 0);
+    NERFX_REQUIRE(lds_bytes * RG::BLOCKS_PER_CU <= 160 * 1024, "model needs %zu bytes of LDS per workgroup", lds_bytes);
     static thread_local size_t configured = 0;
     if (lds_bytes > configured) {
         NERFX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -426,28 +557,43 @@ static int launch_cfg(const MlpArgs& a, size_t lds_bytes, hipStream_t stream) {
     int dev = 0, cus = 256;
     NERFX_HIP(hipGetDevice(&dev));
     NERFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const uint32_t grid = std::min<uint32_t>(a.n_blocks, (uint32_t)cus);   // one persistent workgroup per CU
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WAVES), lds_bytes, stream, a);
+    const uint32_t grid = std::min<uint32_t>(a.n_blocks, (uint32_t)cus * RG::BLOCKS_PER_CU);   // persistent workgroups
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RG::WAVES), lds_bytes, stream, a);
     return launch_status("mlp_fwd_kernel");
 }
 
-template <int PREC, int WAVES, int ACT, bool BIGENC>
-static int launch_width(int wt, const MlpArgs& a, size_t lds, hipStream_t s) {
+template <int PREC, class RG, int ACT, bool BIGENC>
+static int launch_width(int wt, const MlpArgs& a, hipStream_t s) {
     switch (wt) {
-        case 1: return launch_cfg<PREC, 1, WAVES, ACT, BIGENC>(a, lds, s);
-        case 2: return launch_cfg<PREC, 2, WAVES, ACT, BIGENC>(a, lds, s);
-        case 4: return launch_cfg<PREC, 4, WAVES, ACT, BIGENC>(a, lds, s);
-        case 8: return launch_cfg<PREC, 8, WAVES, ACT, BIGENC>(a, lds, s);
+        case 1: return launch_cfg<PREC, 1, RG, ACT, BIGENC>(a, s);
+        case 2: return launch_cfg<PREC, 2, RG, ACT, BIGENC>(a, s);
+        case 4: return launch_cfg<PREC, 4, RG, ACT, BIGENC>(a, s);
+        case 8: return launch_cfg<PREC, 8, RG, ACT, BIGENC>(a, s);
     }
     return fail(NERFX_E_ARG, "unsupported tile count %d", wt);
 }
 
-template <int PREC, int WAVES, bool BIGENC>
-static int launch_activation(int activ, int wt, const MlpArgs& a, size_t lds, hipStream_t s) {
+// Width-256 models with the skip connection and depth 4 or 8 (the reference's configurations).
+template <int PREC, class RG>
+static int launch_fixed_depth(int activ, int hd, const MlpArgs& a, hipStream_t s) {
+#define NERFX_FIXED(ACT_)                                                                  \
+    case ACT_:                                                                             \
+        return hd == 2 ? launch_cfg<PREC, 8, RG, ACT_, false, 2>(a, s) : launch_cfg<PREC, 8, RG, ACT_, false, 4>(a, s);
     switch (activ) {
-        case NERFX_ACT_RELU: return launch_width<PREC, WAVES, NERFX_ACT_RELU, BIGENC>(wt, a, lds, s);
-        case NERFX_ACT_LEAKY_RELU: return launch_width<PREC, WAVES, NERFX_ACT_LEAKY_RELU, BIGENC>(wt, a, lds, s);
-        case NERFX_ACT_SILU: return launch_width<PREC, WAVES, NERFX_ACT_SILU, BIGENC>(wt, a, lds, s);
+        NERFX_FIXED(NERFX_ACT_RELU)
+        NERFX_FIXED(NERFX_ACT_LEAKY_RELU)
+        NERFX_FIXED(NERFX_ACT_SILU)
+    }
+#undef NERFX_FIXED
+    return fail(NERFX_E_ARG, "unknown activation %d", activ);
+}
+
+template <int PREC, class RG, bool BIGENC>
+static int launch_activation(int activ, int wt, const MlpArgs& a, hipStream_t s) {
+    switch (activ) {
+        case NERFX_ACT_RELU: return launch_width<PREC, RG, NERFX_ACT_RELU, BIGENC>(wt, a, s);
+        case NERFX_ACT_LEAKY_RELU: return launch_width<PREC, RG, NERFX_ACT_LEAKY_RELU, BIGENC>(wt, a, s);
+        case NERFX_ACT_SILU: return launch_width<PREC, RG, NERFX_ACT_SILU, BIGENC>(wt, a, s);
     }
     return fail(NERFX_E_ARG, "unknown activation %d", activ);
 }

@@ -52,9 +52,10 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
     p.total_units = unit;
     p.sigw_off = p.n_layers * BIAS_STRIDE;
     p.sigb_off = p.sigw_off + BIAS_STRIDE;
+    auto table_floats = [](int kind, int n) { return ((kind == NERFX_ENC_POSITIONAL ? n : 3 * n) + 3) / 4 * 4; };
     p.tabx_off = p.sigb_off + 4;
-    p.tabd_off = p.tabx_off + MAX_TABLE;
-    p.const_floats = p.tabd_off + MAX_TABLE;
+    p.tabd_off = p.tabx_off + table_floats(d.enc_x_kind, d.enc_x_n);
+    p.const_floats = p.tabd_off + table_floats(d.enc_d_kind, d.enc_d_n);
     return 0;
 }
 
@@ -149,8 +150,8 @@ static int pack_all(nerfx_model* m, const float* const* tensors, hipStream_t str
         vec(tensors[tensor_index(p0, li, true)], p0.layer[li].out_dim, BIAS_STRIDE, li * BIAS_STRIDE);
     vec(tensors[2 + 4 * p0.hd], d.width, BIAS_STRIDE, p0.sigw_off);
     vec(tensors[2 + 4 * p0.hd + 1], 1, 4, p0.sigb_off);
-    vec(tensors[0], d.enc_x_kind == NERFX_ENC_POSITIONAL ? d.enc_x_n : 3 * d.enc_x_n, MAX_TABLE, p0.tabx_off);
-    vec(tensors[1], d.enc_d_kind == NERFX_ENC_POSITIONAL ? d.enc_d_n : 3 * d.enc_d_n, MAX_TABLE, p0.tabd_off);
+    vec(tensors[0], d.enc_x_kind == NERFX_ENC_POSITIONAL ? d.enc_x_n : 3 * d.enc_x_n, p0.tabd_off - p0.tabx_off, p0.tabx_off);
+    vec(tensors[1], d.enc_d_kind == NERFX_ENC_POSITIONAL ? d.enc_d_n : 3 * d.enc_d_n, p0.const_floats - p0.tabd_off, p0.tabd_off);
     return launch_status("pack kernels");
 }
 
