@@ -125,6 +125,35 @@ int nerfx_mlp_fwd_rays(const nerfx_model_t* model, int precision,
                        int64_t n_rays, int n_samples,
                        float* sigma, float* rgb, void* stream);
 
+/* ---- K2b: training forward and backward of the MLP -----------------------------
+ * Replace autograd through NeRF.forward (model.py:68-78) in the reference's
+ * training step (train.py:75-86: render, mse_loss, backward).
+ * The training forward computes what nerfx_mlp_fwd_* computes and records, in
+ * `workspace`, the tape the backward reads: the encoder outputs and every
+ * layer's pre-activation, feature-major, in the precision of the contraction.
+ * nerfx_mlp_bwd then takes d loss / d sigma (M) and d loss / d rgb (M,3) plus
+ * the forward's own sigma / rgb outputs and writes d loss / d parameter for
+ * every Linear into `grads`: a host array of device pointers laid out like
+ * `tensors` of nerfx_model_create (entries 0 and 1, the encoder tables, are
+ * ignored; a NULL entry skips that tensor).  Gradients are written, not
+ * accumulated, and are bit-reproducible from run to run.  The workspace must
+ * not be touched between the two calls; its size depends on the model, the
+ * precision and n_points. */
+int64_t nerfx_mlp_train_workspace_bytes(const nerfx_model_t* model, int precision, int64_t n_points);
+int nerfx_mlp_fwd_train_points(const nerfx_model_t* model, int precision,
+                               const float* x, const float* d, int64_t n_points,
+                               float* sigma, float* rgb,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+int nerfx_mlp_fwd_train_rays(const nerfx_model_t* model, int precision,
+                             const float* ro, const float* rd, const float* t,
+                             int64_t n_rays, int n_samples, float* sigma, float* rgb,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+int nerfx_mlp_bwd(const nerfx_model_t* model, int precision, int64_t n_points,
+                  const float* sigma, const float* rgb,
+                  const float* g_sigma, const float* g_rgb,
+                  void* workspace, int64_t workspace_bytes,
+                  float* const* grads /* host array */, int n_grads, void* stream);
+
 /* ---- K3: alpha compositing ------------------------------------------------
  * Replaces segment_lengths (ray.py:60-66), raymarch_volume + exclusive_cumprod
  * (renderer.py:23-26, :50-57) and the depth reduction (renderer.py:203).

@@ -39,6 +39,10 @@ SIGNATURES = {
     "nerfx_encode_fwd": (_i, [_p, _l, _i, _i, _p, _p, _p]),
     "nerfx_mlp_fwd_points": (_i, [_p, _i, _p, _p, _l, _p, _p, _p]),
     "nerfx_mlp_fwd_rays": (_i, [_p, _i, _p, _p, _p, _l, _i, _p, _p, _p]),
+    "nerfx_mlp_train_workspace_bytes": (_l, [_p, _i, _l]),
+    "nerfx_mlp_fwd_train_points": (_i, [_p, _i, _p, _p, _l, _p, _p, _p, _l, _p]),
+    "nerfx_mlp_fwd_train_rays": (_i, [_p, _i, _p, _p, _p, _l, _i, _p, _p, _p, _l, _p]),
+    "nerfx_mlp_bwd": (_i, [_p, _i, _l, _p, _p, _p, _p, _p, _l, C.POINTER(_p), _i, _p]),
     "nerfx_composite_fwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
     "nerfx_composite_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p]),
     "nerfx_segment_lengths": (_i, [_p, _p, _l, _i, _p, _p]),

@@ -97,6 +97,9 @@ struct LayerPlan {
     int enc_seg;        // units of one group's encoder segment (padded to pieces)
     int chain_seg;      // units of one group's chained segment (padded to pieces)
     int64_t unit0;      // first unit of this layer in the stream
+    // Backward-stream layers carry W^T of forward layer `src_layer`: row i, input k is
+    // W[k][src_col0 + i] of a weight with leading dimension src_ld.
+    int transposed, src_layer, src_ld, src_col0;
 };
 
 struct ModelPlan {
@@ -111,6 +114,16 @@ struct ModelPlan {
     int64_t total_units;   // whole stream
     // const block (floats): [layer biases | sigma w | sigma b | table x | table d]
     int sigw_off, sigb_off, tabx_off, tabd_off, const_floats;
+    // Backward stream: the input-gradient chain rgb.2 -> rgb.0 -> features -> trunk (last .. 1),
+    // each layer the transposed chained block of its forward layer.
+    int n_bwd;
+    LayerPlan bwd[MAX_LAYERS];
+    int64_t bwd_units;
+    // Training tape rows (see Tape in mlp_fwd_impl.hpp).  The pre-activation tape and the
+    // gradient tape share one row map: encoder slots of x and d, then 32 rows per output tile
+    // of every layer but rgb.2, then the gradients at rgb.2's 3 outputs and at the density
+    // head's pre-activation (gradient tape only).
+    int tape_ex_row, tape_ed_row, tape_z_row[MAX_LAYERS], tape_go_row, tape_gs_row, tape_rows;
 };
 
 __host__ __device__ inline int units_of(const LayerPlan& L) { return (L.n_tiles / L.group) * (L.enc_seg + L.chain_seg); }
@@ -118,12 +131,19 @@ __host__ __device__ inline int units_of(const LayerPlan& L) { return (L.n_tiles 
 // Fills `p` from a model description; returns 0 or an error code.
 int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p);
 
+// Samples per tape row for n_points samples: whole workgroup blocks of either kernel family
+// and whole sample chunks of the weight-gradient kernel.
+inline uint64_t tape_m_pad(int64_t n_points) { return ((uint64_t)n_points + 255) / 256 * 256; }
+
 }  // namespace nerfx
 
 // The opaque handle of include/nerfx.h.
 struct nerfx_model {
     nerfx::ModelPlan plan[2];          // indexed by NERFX_PREC_*
     void* stream_dev[2];               // packed unit streams
+    void* stream_bwd_dev[2];           // packed backward (transposed) unit streams
+    void* wtasks_dev[2];               // weight-gradient task tables (mlp_wgrad.hip)
+    int n_wtasks[2];
     float* const_dev;                  // const block (same for both precisions)
     int n_tensors;
     int device;

@@ -1,0 +1,7 @@
+// fp32 MFMA instantiations of the MLP's input-gradient chain.
+#include "mlp_bwd_impl.hpp"
+namespace nerfx {
+int launch_mlp_bwd_fp32(int activ, int wt, const BwdArgs& a, hipStream_t s) {
+    return launch_bwd_activation<NERFX_PREC_FP32, RingFp32>(activ, wt, a, s);
+}
+}  // namespace nerfx

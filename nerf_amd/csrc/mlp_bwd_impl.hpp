@@ -1,0 +1,208 @@
+// K2b, part 1: the input-gradient chain of the fused MLP (autograd of model.py:68-78).
+//
+// Same orientation and weight ring as the forward kernel: a wavefront owns 32 samples, the
+// gradient at a layer's pre-activation (Gz, 32 x 32 accumulator tiles with the sample on the
+// lane) is converted in registers into the B operand of the next product
+//     G_{l-1} = W_l[:, chained columns]^T . Gz_l ,      Gz_{l-1} = G_{l-1} * act'(z_{l-1}),
+// and the weights come from the model's BACKWARD unit stream (transposed blocks, packed by
+// model.hip).  z is read from the tape the training forward wrote; every Gz is written to the
+// gradient tape (same row map), from which the weight-gradient kernel forms dW = Gz . X^T.
+// Gradients with respect to the encodings are never formed: positions and directions are
+// inputs of the reference's training step, not parameters.
+#pragma once
+#include "mlp_fwd_impl.hpp"
+
+namespace nerfx {
+
+struct BwdArgs {
+    const char* stream;          // packed backward units
+    const float* consts;         // const block (global): the density head's weights are used
+    const void* ztape;           // pre-activations (training forward)
+    void* gtape;                 // receives the pre-activation gradients
+    uint64_t m_pad;              // elements per tape row
+    const float* g_sigma;        // (M)
+    const float* g_rgb;          // (M,3)
+    const float* sigma;          // (M)   forward outputs: the output activations' derivatives
+    const float* rgb;            // (M,3) are formed from them
+    uint32_t n_points, n_blocks, n_pieces;
+    int hd, sigw_off, const_floats;
+    int z_row[MAX_LAYERS], go_row, gs_row;
+};
+
+template <int PREC, int ACT>
+__device__ __forceinline__ float activation_slope(float z) {
+    if (ACT == NERFX_ACT_RELU) return z > 0.0f ? 1.0f : 0.0f;
+    if (ACT == NERFX_ACT_LEAKY_RELU) return z > 0.0f ? 1.0f : 0.01f;
+    if (ACT == NERFX_ACT_SILU) {
+        const float s = 1.0f / (1.0f + Prec<PREC>::expneg(z));
+        return s * (1.0f + z * (1.0f - s));
+    }
+    return 1.0f;
+}
+
+// One step of the chain.  hin: Gz of the later layer (CT tiles); the product lands in NT
+// tiles, gets the density head's contribution (SIGMA: + w_sigma[f] * gs), is multiplied by
+// act'(z) of the rows it belongs to (ACT < 0: a plain Linear, no factor), is stored to the
+// gradient tape at `row` and becomes hout.
+template <int PREC, class RG, int ACT, int NT, int CT, bool SIGMA, int HN_IN, int HN_OUT>
+__device__ __forceinline__ void linear_bwd(WeightRing<RG>& ring, int h, const typename Prec<PREC>::Frag (&hin)[HN_IN],
+                                           typename Prec<PREC>::Frag (&hout)[HN_OUT], const Tape<PREC>& ztape,
+                                           const Tape<PREC>& gtape, int row, lds_floats_t sigw, float gs) {
+    using P = Prec<PREC>;
+    constexpr int NG = group_tiles(PREC, NT);
+    constexpr int SYNC_PIECES = RG::SYNC;
+    constexpr int KB_PER_PIECE = PIECE_UNITS / NG;
+    constexpr int CHAIN_KU = CT * P::UPT;
+    constexpr int CHAIN_PIECES = pad_to_piece(CHAIN_KU * NG) / PIECE_UNITS;
+    static_assert(CHAIN_KU <= HN_IN && NT * P::UPT <= HN_OUT, "fragment arrays too small");
+#pragma unroll
+    for (int grp = 0; grp < NT / NG; ++grp) {
+        f32x16 acc[NG];
+#pragma unroll
+        for (int t = 0; t < NG; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+        for (int p0 = 0; p0 < CHAIN_PIECES; p0 += SYNC_PIECES) {
+            constexpr int TAIL = CHAIN_PIECES % SYNC_PIECES ? CHAIN_PIECES % SYNC_PIECES : SYNC_PIECES;
+            const int ku0 = p0 * KB_PER_PIECE;
+            if (CHAIN_PIECES - p0 >= SYNC_PIECES) {
+                constexpr int KU = SYNC_PIECES * KB_PER_PIECE;
+                ring.template acquire<SYNC_PIECES>();
+                run_units<PREC, RG, NG, KU * NG>(ring, acc, [&](int k) { return hin[ku0 + k]; });
+                ring.template release<SYNC_PIECES>();
+            } else {
+                constexpr int KU = CHAIN_KU - (CHAIN_PIECES - TAIL) * KB_PER_PIECE;
+                ring.template acquire<TAIL>();
+                run_units<PREC, RG, NG, (KU > 0 ? KU : 1) * NG>(ring, acc, [&](int k) { return hin[ku0 + k]; });
+                ring.template release<TAIL>();
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            const int tile = grp * NG + t;
+            if (SIGMA) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 w = NERFX_LDS_VEC(f32x4, sigw + 32 * tile + 8 * g + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = fmaf(w[i], gs, acc[t][4 * g + i]);
+                }
+            }
+            if (ACT >= 0) {
+                const f32x16 z = ztape.load_tile(row + 32 * tile, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] *= activation_slope<PREC, ACT>(z[r]);
+            }
+            gtape.store_tile(row + 32 * tile, h, acc[t]);
+#pragma unroll
+            for (int s = 0; s < P::UPT; ++s) hout[tile * P::UPT + s] = P::from_acc(acc[t], s);
+        }
+    }
+}
+
+template <int PREC, int WT, class RG, int ACT>
+__global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) void mlp_bwd_kernel(const BwdArgs a) {
+    constexpr int WAVES = RG::WAVES;
+    using P = Prec<PREC>;
+    using Frag = typename P::Frag;
+    constexpr int RT = WT > 1 ? WT / 2 : 1;
+    constexpr int HN = WT * P::UPT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __attribute__((address_space(3))) float* cst = (__attribute__((address_space(3))) float*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    WeightRing<RG> ring;                                          // LDS: [const block | weight ring]
+    ring.init(a.stream, (lds_bytes_t)smem + a.const_floats * (int)sizeof(float), a.n_pieces, wave, lane);
+    for (int i = tid; i < a.const_floats; i += 64 * WAVES) cst[i] = a.consts[i];
+    __syncthreads();
+    const lds_floats_t sigw = cst + a.sigw_off;
+    const int feat = 2 * a.hd;                                    // index of the `features` layer
+
+    for (uint32_t blk = blockIdx.x; blk < a.n_blocks; blk += gridDim.x) {
+        const uint32_t m = blk * (32 * WAVES) + wave * 32 + (lane & 31);
+        const bool valid = m < a.n_points;
+        // Output activations, differentiated through their outputs:
+        //   rgb = 1.002 s(o) - 0.001  (activations.py:18-20)  => d rgb / d o = 1.002 s (1 - s)
+        //   sigma = softplus(x - 1)   (activations.py:33-35)  => d sigma / d x = 1 - exp(-sigma)
+        float go[3] = {0.0f, 0.0f, 0.0f}, gs = 0.0f;              // tail lanes contribute nothing
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float s = (a.rgb[3 * (size_t)m + c] + 0.001f) * (1.0f / 1.002f);
+                go[c] = a.g_rgb[3 * (size_t)m + c] * (1.002f * s * (1.0f - s));
+            }
+            gs = a.g_sigma[m] * -expm1f(-a.sigma[m]);
+        }
+        const Tape<PREC> zt{(typename Tape<PREC>::T*)a.ztape, a.m_pad, m};
+        const Tape<PREC> gt{(typename Tape<PREC>::T*)a.gtape, a.m_pad, m};
+        if (h == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) *gt.at(a.go_row + c) = (typename Tape<PREC>::T)go[c];
+            *gt.at(a.gs_row) = (typename Tape<PREC>::T)gs;
+        }
+        // rgb.2's gradient as a 32-row tile: rows 0..2 are registers 0..2 of lane half 0
+        f32x16 top;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) top[r] = 0.0f;
+        if (h == 0) { top[0] = go[0]; top[1] = go[1]; top[2] = go[2]; }
+        Frag A[HN], B[HN];
+#pragma unroll
+        for (int s = 0; s < P::UPT; ++s) A[s] = P::from_acc(top, s);
+        linear_bwd<PREC, RG, ACT, RT, 1, false>(ring, h, A, B, zt, gt, a.z_row[feat + 1], sigw, gs);   // -> rgb.0
+        linear_bwd<PREC, RG, -1, WT, RT, false>(ring, h, B, A, zt, gt, a.z_row[feat], sigw, gs);       // -> features
+        linear_bwd<PREC, RG, ACT, WT, WT, true>(ring, h, A, B, zt, gt, a.z_row[feat - 1], sigw, gs);   // -> last trunk layer
+        // trunk layers feat-1 .. 1, each producing the gradient of the layer below it
+        int li = feat - 1;
+        if (li >= 1) {
+            linear_bwd<PREC, RG, ACT, WT, WT, false>(ring, h, B, A, zt, gt, a.z_row[li - 1], sigw, gs);
+            --li;
+        }
+        for (; li >= 2; li -= 2) {
+            linear_bwd<PREC, RG, ACT, WT, WT, false>(ring, h, A, B, zt, gt, a.z_row[li - 1], sigw, gs);
+            linear_bwd<PREC, RG, ACT, WT, WT, false>(ring, h, B, A, zt, gt, a.z_row[li - 2], sigw, gs);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int PREC, int WT, class RG, int ACT>
+static int launch_bwd_cfg(const BwdArgs& a, hipStream_t stream) {
+    auto kern = mlp_bwd_kernel<PREC, WT, RG, ACT>;
+    const size_t lds_bytes = (size_t)a.const_floats * sizeof(float) + (size_t)RG::PIECES * PIECE_UNITS * UNIT_BYTES;
+    NERFX_REQUIRE(lds_bytes <= 160 * 1024, "model needs %zu bytes of LDS per workgroup", lds_bytes);
+    static thread_local size_t configured = 0;
+    if (lds_bytes > configured) {
+        NERFX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        configured = lds_bytes;
+    }
+    int dev = 0, cus = 256;
+    NERFX_HIP(hipGetDevice(&dev));
+    NERFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const uint32_t grid = std::min<uint32_t>(a.n_blocks, (uint32_t)cus * RG::BLOCKS_PER_CU);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RG::WAVES), lds_bytes, stream, a);
+    return launch_status("mlp_bwd_kernel");
+}
+
+template <int PREC, class RG, int ACT>
+static int launch_bwd_width(int wt, const BwdArgs& a, hipStream_t s) {
+    switch (wt) {
+        case 1: return launch_bwd_cfg<PREC, 1, RG, ACT>(a, s);
+        case 2: return launch_bwd_cfg<PREC, 2, RG, ACT>(a, s);
+        case 4: return launch_bwd_cfg<PREC, 4, RG, ACT>(a, s);
+        case 8: return launch_bwd_cfg<PREC, 8, RG, ACT>(a, s);
+    }
+    return fail(NERFX_E_ARG, "unsupported tile count %d", wt);
+}
+
+template <int PREC, class RG>
+static int launch_bwd_activation(int activ, int wt, const BwdArgs& a, hipStream_t s) {
+    switch (activ) {
+        case NERFX_ACT_RELU: return launch_bwd_width<PREC, RG, NERFX_ACT_RELU>(wt, a, s);
+        case NERFX_ACT_LEAKY_RELU: return launch_bwd_width<PREC, RG, NERFX_ACT_LEAKY_RELU>(wt, a, s);
+        case NERFX_ACT_SILU: return launch_bwd_width<PREC, RG, NERFX_ACT_SILU>(wt, a, s);
+    }
+    return fail(NERFX_E_ARG, "unknown activation %d", activ);
+}
+
+}  // namespace nerfx

@@ -1,5 +1,5 @@
 // K2 entry points: validate, fill the launch arguments from the model plan, dispatch.
-#include "mlp_fwd_impl.hpp"
+#include "mlp_bwd_impl.hpp"
 
 namespace nerfx {
 int launch_mlp_bf16(int activ, int wt, const MlpArgs& a, hipStream_t s);
@@ -8,6 +8,13 @@ int launch_mlp_bf16_bigenc(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_fp32_bigenc(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
 int launch_mlp_fp32_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
+int launch_mlp_bf16_train(int activ, int wt, const MlpArgs& a, hipStream_t s);
+int launch_mlp_fp32_train(int activ, int wt, const MlpArgs& a, hipStream_t s);
+int launch_mlp_bwd_bf16(int activ, int wt, const BwdArgs& a, hipStream_t s);
+int launch_mlp_bwd_fp32(int activ, int wt, const BwdArgs& a, hipStream_t s);
+int64_t wgrad_partial_bytes(const nerfx_model* m, int prec, uint64_t m_pad);
+int launch_wgrad(const nerfx_model* m, int prec, uint64_t m_pad, const void* ztape, const void* gtape, float* partial,
+                 float* const* grads, int n_grads, hipStream_t stream);
 }  // namespace nerfx
 
 using namespace nerfx;
@@ -17,7 +24,7 @@ static unsigned long long* g_stamps = nullptr;
 extern "C" void nerfx_debug_set_stamps(unsigned long long* device_buffer) { g_stamps = device_buffer; }
 
 static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0, const float* p1, const float* t,
-                      int64_t n_points, int n_samples, float* sigma, float* rgb, void* stream) {
+                      int64_t n_points, int n_samples, float* sigma, float* rgb, void* stream, void* tape = nullptr) {
     NERFX_REQUIRE(model != nullptr, "model is NULL");
     NERFX_REQUIRE(precision == NERFX_PREC_FP32 || precision == NERFX_PREC_BF16, "unknown precision %d", precision);
     NERFX_REQUIRE(n_points >= 0 && n_points < (int64_t)1 << 31, "n_points %lld out of range [0, 2^31)", (long long)n_points);
@@ -39,6 +46,15 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
     a.sigw_off = p.sigw_off; a.sigb_off = p.sigb_off; a.tabx_off = p.tabx_off; a.tabd_off = p.tabd_off;
     a.const_floats = p.const_floats;
     a.stamps = g_stamps;
+    if (tape) {                                                     // training forward: record the tape
+        NERFX_REQUIRE(rgb != nullptr, "the training forward needs the colour output");
+        a.tape = tape;
+        a.tape_m_pad = tape_m_pad(n_points);
+        a.n_blocks = (uint32_t)(a.tape_m_pad / (32 * waves));       // pad columns are written too
+        a.tape_ex_row = p.tape_ex_row; a.tape_ed_row = p.tape_ed_row;
+        for (int li = 0; li < p.n_layers; ++li) a.tape_z_row[li] = p.tape_z_row[li];
+        return (precision == NERFX_PREC_BF16 ? launch_mlp_bf16_train : launch_mlp_fp32_train)(p.desc.activ, p.wt, a, (hipStream_t)stream);
+    }
     // encoders that fit the kernels' register cache take the fast instantiations
     const bool big = a.ex_units > ENC_BLOCK || a.ed_units > ENC_BLOCK;
     if (!big && p.wt == 8 && p.desc.resid && (p.hd == 2 || p.hd == 4))          // compile-time depth
@@ -59,4 +75,88 @@ extern "C" int nerfx_mlp_fwd_rays(const nerfx_model_t* model, int precision, con
     NERFX_REQUIRE(n_rays >= 0 && n_samples >= 1, "bad ray/sample count");
     NERFX_REQUIRE(n_rays == 0 || t != nullptr, "t is NULL");
     return mlp_launch(model, precision, ro, rd, t, n_rays * n_samples, n_samples, sigma, rgb, stream);
+}
+
+// ---- training: forward with tape, then backward ------------------------------------------
+namespace {
+struct TrainWorkspace {
+    char *ztape, *gtape;
+    float* partial;
+    uint64_t m_pad;
+    int64_t bytes;
+};
+TrainWorkspace carve_train(const nerfx_model_t* model, int precision, int64_t n_points, void* base) {
+    const ModelPlan& p = model->plan[precision];
+    TrainWorkspace w{};
+    w.m_pad = tape_m_pad(n_points);
+    const int64_t tape_bytes = (int64_t)p.tape_rows * (int64_t)w.m_pad * (precision == NERFX_PREC_BF16 ? 2 : 4);
+    char* c = (char*)base;
+    w.ztape = c; c += tape_bytes;
+    w.gtape = c; c += tape_bytes;
+    w.partial = (float*)c; c += wgrad_partial_bytes(model, precision, w.m_pad);
+    w.bytes = c - (char*)base;
+    return w;
+}
+}  // namespace
+
+extern "C" int64_t nerfx_mlp_train_workspace_bytes(const nerfx_model_t* model, int precision, int64_t n_points) {
+    if (!model || (precision != NERFX_PREC_FP32 && precision != NERFX_PREC_BF16) || n_points < 0) return -1;
+    return carve_train(model, precision, n_points, nullptr).bytes;
+}
+
+static int train_fwd(const nerfx_model_t* model, int precision, const float* p0, const float* p1, const float* t,
+                     int64_t n_points, int n_samples, float* sigma, float* rgb, void* workspace,
+                     int64_t workspace_bytes, void* stream) {
+    NERFX_REQUIRE(model != nullptr, "model is NULL");
+    NERFX_REQUIRE(precision == NERFX_PREC_FP32 || precision == NERFX_PREC_BF16, "unknown precision %d", precision);
+    NERFX_REQUIRE(n_points >= 0 && n_points < (int64_t)1 << 31, "n_points %lld out of range [0, 2^31)", (long long)n_points);
+    if (n_points == 0) return 0;
+    NERFX_REQUIRE(workspace && workspace_bytes >= nerfx_mlp_train_workspace_bytes(model, precision, n_points),
+                  "training workspace too small: %lld < %lld bytes", (long long)workspace_bytes,
+                  (long long)nerfx_mlp_train_workspace_bytes(model, precision, n_points));
+    const TrainWorkspace w = carve_train(model, precision, n_points, workspace);
+    return mlp_launch(model, precision, p0, p1, t, n_points, n_samples, sigma, rgb, stream, w.ztape);
+}
+
+extern "C" int nerfx_mlp_fwd_train_points(const nerfx_model_t* model, int precision, const float* x, const float* d,
+                                          int64_t n_points, float* sigma, float* rgb, void* workspace,
+                                          int64_t workspace_bytes, void* stream) {
+    return train_fwd(model, precision, x, d, nullptr, n_points, 1, sigma, rgb, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nerfx_mlp_fwd_train_rays(const nerfx_model_t* model, int precision, const float* ro, const float* rd,
+                                        const float* t, int64_t n_rays, int n_samples, float* sigma, float* rgb,
+                                        void* workspace, int64_t workspace_bytes, void* stream) {
+    NERFX_REQUIRE(n_rays >= 0 && n_samples >= 1, "bad ray/sample count");
+    NERFX_REQUIRE(n_rays == 0 || t != nullptr, "t is NULL");
+    return train_fwd(model, precision, ro, rd, t, n_rays * n_samples, n_samples, sigma, rgb, workspace, workspace_bytes, stream);
+}
+
+extern "C" int nerfx_mlp_bwd(const nerfx_model_t* model, int precision, int64_t n_points, const float* sigma,
+                             const float* rgb, const float* g_sigma, const float* g_rgb, void* workspace,
+                             int64_t workspace_bytes, float* const* grads, int n_grads, void* stream) {
+    NERFX_REQUIRE(model != nullptr, "model is NULL");
+    NERFX_REQUIRE(precision == NERFX_PREC_FP32 || precision == NERFX_PREC_BF16, "unknown precision %d", precision);
+    NERFX_REQUIRE(n_points > 0 && n_points < (int64_t)1 << 31, "n_points %lld out of range (0, 2^31)", (long long)n_points);
+    NERFX_REQUIRE(sigma && rgb && g_sigma && g_rgb && grads, "NULL input or output");
+    NERFX_REQUIRE(n_grads == model->n_tensors, "expected %d gradient slots, got %d", model->n_tensors, n_grads);
+    NERFX_REQUIRE(workspace && workspace_bytes >= nerfx_mlp_train_workspace_bytes(model, precision, n_points),
+                  "training workspace too small");
+    const ModelPlan& p = model->plan[precision];
+    const TrainWorkspace w = carve_train(model, precision, n_points, workspace);
+    const int waves = precision == NERFX_PREC_BF16 ? RingBf16::WAVES : RingFp32::WAVES;
+    BwdArgs a{};
+    a.stream = (const char*)model->stream_bwd_dev[precision];
+    a.consts = model->const_dev;
+    a.ztape = w.ztape; a.gtape = w.gtape; a.m_pad = w.m_pad;
+    a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.sigma = sigma; a.rgb = rgb;
+    a.n_points = (uint32_t)n_points;
+    a.n_blocks = (uint32_t)(w.m_pad / (32 * waves));
+    a.n_pieces = (uint32_t)(p.bwd_units / PIECE_UNITS);
+    a.hd = p.hd; a.sigw_off = p.sigw_off; a.const_floats = p.const_floats;
+    for (int li = 0; li < p.n_layers; ++li) a.z_row[li] = p.tape_z_row[li];
+    a.go_row = p.tape_go_row; a.gs_row = p.tape_gs_row;
+    if (int rc = (precision == NERFX_PREC_BF16 ? launch_mlp_bwd_bf16 : launch_mlp_bwd_fp32)(p.desc.activ, p.wt, a, (hipStream_t)stream))
+        return rc;
+    return launch_wgrad(model, precision, w.m_pad, w.ztape, w.gtape, w.partial, grads, n_grads, (hipStream_t)stream);
 }

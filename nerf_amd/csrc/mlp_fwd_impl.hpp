@@ -22,6 +22,8 @@
 // sample are computed once per block into registers and consumed by layer 0, the
 // skip layer and rgb.0; they are never stored.
 #pragma once
+#include <type_traits>
+
 #include "mlp.hpp"
 
 namespace nerfx {
@@ -51,6 +53,9 @@ struct MlpArgs {
     int ex_kind, ex_n, ex_units, ed_kind, ed_n, ed_units;
     int sigw_off, sigb_off, tabx_off, tabd_off, const_floats;
     unsigned long long* stamps;  // diagnostic builds: 6 cycle buckets, else NULL
+    void* tape;                  // training forward: feature-major tape (see Tape), else NULL
+    uint64_t tape_m_pad;         // elements per tape row
+    int tape_ex_row, tape_ed_row, tape_z_row[MAX_LAYERS];   // first row of each encoder / layer
 };
 
 // ---- optional in-kernel cycle accounting (diagnostic builds only: -DNERFX_STAMPS) -------
@@ -75,6 +80,30 @@ struct Stamps {
 #endif
 };
 enum { ST_PROLOGUE = 0, ST_ACQUIRE = 1, ST_RUN = 2, ST_EPILOGUE = 3, ST_HEADS = 4, ST_ENCODE = 5 };
+
+// ---- training tape -------------------------------------------------------------------------
+// Feature-major scratch in HBM shared by the training forward, the backward chain and the
+// weight-gradient kernels: row f holds feature f of every sample (`m_pad` elements, bf16 or
+// fp32 with the kernel's precision).  A wavefront holds a 32x32 tile with its sample on the
+// lane, so register r of a tile is one element of row (r&3) + 8 (r>>2) + 4 h.
+template <int PREC>
+struct Tape {
+    using T = typename std::conditional<PREC == NERFX_PREC_BF16, __bf16, float>::type;
+    T* base;
+    uint64_t m_pad;
+    uint32_t m;                  // this lane's sample column
+    __device__ __forceinline__ T* at(int row) const { return base + (uint64_t)row * m_pad + m; }
+    __device__ __forceinline__ void store_tile(int row0, int h, const f32x16& v) const {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *at(row0 + (r & 3) + 8 * (r >> 2) + 4 * h) = (T)v[r];
+    }
+    __device__ __forceinline__ f32x16 load_tile(int row0, int h) const {
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = (float)*at(row0 + (r & 3) + 8 * (r >> 2) + 4 * h);
+        return v;
+    }
+};
 
 // ---- LDS weight ring ---------------------------------------------------------------
 template <class RG>
@@ -297,12 +326,16 @@ constexpr bool uses_stash() { return PREC == NERFX_PREC_BF16 && !BIGENC && WT >=
 //   with_enc: this layer's stream carries an encoder segment (wave-uniform)
 //   SIGMA: also accumulate the density head's dot product on the fp32 activations
 //   raw  : if non-null (NT == 1 only) receives the fp32 accumulator tile instead of hout
-template <int PREC, class RG, int ACT, bool BIGENC, int NT, int CT, bool SIGMA, bool STASH = false, int HN_IN = 0, int HN_OUT = 0>
+//   ztape: training forward (TRAIN): the pre-activation output goes to tape rows zrow..;
+//          with an encoder segment, its B operands go to rows erow.. in slot order
+template <int PREC, class RG, int ACT, bool BIGENC, int NT, int CT, bool SIGMA, bool STASH = false, bool TRAIN = false,
+          int HN_IN = 0, int HN_OUT = 0>
 __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias, int h,
                                         const typename Prec<PREC>::Frag (&hin)[HN_IN],
                                         typename Prec<PREC>::Frag (&hout)[HN_OUT],
                                         bool with_enc, const Encoding<PREC>& enc, lds_floats_t sigw,
-                                        Stamps& st, f32x16* raw = nullptr, uint32_t stash = 0) {
+                                        Stamps& st, f32x16* raw = nullptr, uint32_t stash = 0,
+                                        const Tape<PREC>* ztape = nullptr, int zrow = 0, int erow = -1) {
     using P = Prec<PREC>;
     constexpr int NG = group_tiles(PREC, NT);
     constexpr int SYNC_PIECES = RG::SYNC;
@@ -346,6 +379,15 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
                     typename P::Frag eb[ENC_BLOCK];
 #pragma unroll
                     for (int u = 0; u < ENC_BLOCK; ++u) eb[u] = enc.eval(u0 + u);
+                    if constexpr (TRAIN) {
+                        if (grp == 0 && erow >= 0) {               // slot s of the encoding -> tape row erow + s
+#pragma unroll
+                            for (int u = 0; u < ENC_BLOCK; ++u)
+#pragma unroll
+                                for (int e = 0; e < P::SPUH; ++e)
+                                    *ztape->at(erow + enc_unit_slot(PREC, u0 + u, h, e)) = eb[u][e];
+                        }
+                    }
                     ring.template acquire<ENC_PIECES>();
                     run_units<PREC, RG, NG, ENC_BLOCK * NG>(ring, acc, [&](int u) { return eb[u]; });
                     ring.template release<ENC_PIECES>();
@@ -375,6 +417,10 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
                 st.mark(ST_RUN);
                 ring.template release<TAIL>();
             }
+        }
+        if constexpr (TRAIN) {
+#pragma unroll
+            for (int t = 0; t < NG; ++t) ztape->store_tile(zrow + 32 * (grp * NG + t), h, acc[t]);
         }
         // epilogue: activation, density dot, conversion to the next layer's operands
         constexpr bool packed_relu = ACT == NERFX_ACT_RELU && P::PACKED_RELU && !SIGMA;
@@ -413,8 +459,10 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
 // connection on): the block body is then straight-line code, which hipcc allocates without
 // the loop-carried copies of the activation fragments that the runtime-depth form (HD = 0)
 // needs and spills.
-template <int PREC, int WT, class RG, int ACT, bool BIGENC, int HD>
+// TRAIN: also record the tape the backward kernels read (pre-activations and encodings).
+template <int PREC, int WT, class RG, int ACT, bool BIGENC, int HD, bool TRAIN = false>
 __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) void mlp_fwd_kernel(const MlpArgs a) {
+    static_assert(!TRAIN || (BIGENC && HD == 0), "the training forward uses the general encoder / depth paths");
     constexpr int WAVES = RG::WAVES;
     using P = Prec<PREC>;
     using Frag = typename P::Frag;
@@ -480,11 +528,13 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         st.mark(ST_ENCODE);
         Frag A[HN], B[HN];                                        // ping-pong activation fragments
         float dot = 0.0f;
+        Tape<PREC> tape{(typename Tape<PREC>::T*)a.tape, a.tape_m_pad, m};   // m < m_pad also for tail lanes
+        const Tape<PREC>* zt = TRAIN ? &tape : nullptr;
         // ---- fc_1 then fc_2; fc_2's first layer optionally sees [phi_x | h] (model.py:71-73).
         // Layer 0 writes A; the remaining 2 hd - 1 trunk layers alternate A -> B, B -> A, so the
         // last one always lands in B.
-        if (last == 0) dot = linear<PREC, RG, ACT, BIGENC, WT, 0, true, STASH>(ring, cst, h, A, B, true, enc, sigw, st, nullptr, stash);
-        else linear<PREC, RG, ACT, BIGENC, WT, 0, false, STASH>(ring, cst, h, B, A, true, enc, sigw, st, nullptr, stash);
+        if (last == 0) dot = linear<PREC, RG, ACT, BIGENC, WT, 0, true, STASH, TRAIN>(ring, cst, h, A, B, true, enc, sigw, st, nullptr, stash, zt, a.tape_z_row[0], a.tape_ex_row);
+        else linear<PREC, RG, ACT, BIGENC, WT, 0, false, STASH, TRAIN>(ring, cst, h, B, A, true, enc, sigw, st, nullptr, stash, zt, a.tape_z_row[0], a.tape_ex_row);
         const int skip = resid ? hd : -1;                          // the layer that sees phi_x again
         auto refresh = [&](int li) {                               // register-resident encodings only
             if (!STASH && li == skip) {
@@ -497,13 +547,13 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
 #pragma unroll
         for (; li + 1 <= last; li += 2) {
             refresh(li);
-            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH>(ring, cst + li * BIAS_STRIDE, h, A, B, li == skip, enc, sigw, st, nullptr, stash);
+            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN>(ring, cst + li * BIAS_STRIDE, h, A, B, li == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_row[li]);
             refresh(li + 1);
-            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH>(ring, cst + (li + 1) * BIAS_STRIDE, h, B, A, li + 1 == skip, enc, sigw, st, nullptr, stash);
+            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN>(ring, cst + (li + 1) * BIAS_STRIDE, h, B, A, li + 1 == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_row[li + 1]);
         }
         if (last > 0) {
             refresh(last);
-            dot = linear<PREC, RG, ACT, BIGENC, WT, WT, true, STASH>(ring, cst + last * BIAS_STRIDE, h, A, B, last == skip, enc, sigw, st, nullptr, stash);
+            dot = linear<PREC, RG, ACT, BIGENC, WT, WT, true, STASH, TRAIN>(ring, cst + last * BIAS_STRIDE, h, A, B, last == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_row[last]);
         }
         // ---- density head (model.py:75, activations.py:33-35) ------------------------------
         st.mark(ST_EPILOGUE);
@@ -518,11 +568,11 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         if (colour) {
             li = last + 1;
             // ---- features: Linear without activation (model.py:51, :76): B -> A ------------
-            linear<PREC, RG, -1, BIGENC, WT, WT, false>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, st);
+            linear<PREC, RG, -1, BIGENC, WT, WT, false, false, TRAIN>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, st, nullptr, 0, zt, a.tape_z_row[li]);
             ++li;
             // ---- rgb.0 on [phi_d | features] (model.py:53, :76): A -> B ---------------------
             { st.mark(ST_EPILOGUE); enc.template prepare<BIGENC>(a.ed_kind, a.ed_n, a.ed_units, cst + a.tabd_off, h, dx, dy, dz); st.mark(ST_ENCODE); }
-            linear<PREC, RG, ACT, BIGENC, RT, WT, false>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw, st);
+            linear<PREC, RG, ACT, BIGENC, RT, WT, false, false, TRAIN>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw, st, nullptr, 0, zt, a.tape_z_row[li], a.tape_ed_row);
             ++li;
             // ---- rgb.2 + widened sigmoid (model.py:54, activations.py:18-20) ----------------
             f32x16 out;
@@ -543,9 +593,9 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int PREC, int WT, class RG, int ACT, bool BIGENC, int HD = 0>
+template <int PREC, int WT, class RG, int ACT, bool BIGENC, int HD = 0, bool TRAIN = false>
 static int launch_cfg(const MlpArgs& a, hipStream_t stream) {
-    auto kern = mlp_fwd_kernel<PREC, WT, RG, ACT, BIGENC, HD>;
+    auto kern = mlp_fwd_kernel<PREC, WT, RG, ACT, BIGENC, HD, TRAIN>;
     const size_t lds_bytes = (size_t)a.const_floats * sizeof(float) + (size_t)RG::PIECES * PIECE_UNITS * UNIT_BYTES +
                              (uses_stash<PREC, WT, BIGENC>() ? (size_t)RG::WAVES * STASH_BYTES_PER_WAVE : 0);
     NERFX_REQUIRE(lds_bytes * RG::BLOCKS_PER_CU <= 160 * 1024, "model needs %zu bytes of LDS per workgroup", lds_bytes);
@@ -562,13 +612,13 @@ static int launch_cfg(const MlpArgs& a, hipStream_t stream) {
     return launch_status("mlp_fwd_kernel");
 }
 
-template <int PREC, class RG, int ACT, bool BIGENC>
+template <int PREC, class RG, int ACT, bool BIGENC, bool TRAIN = false>
 static int launch_width(int wt, const MlpArgs& a, hipStream_t s) {
     switch (wt) {
-        case 1: return launch_cfg<PREC, 1, RG, ACT, BIGENC>(a, s);
-        case 2: return launch_cfg<PREC, 2, RG, ACT, BIGENC>(a, s);
-        case 4: return launch_cfg<PREC, 4, RG, ACT, BIGENC>(a, s);
-        case 8: return launch_cfg<PREC, 8, RG, ACT, BIGENC>(a, s);
+        case 1: return launch_cfg<PREC, 1, RG, ACT, BIGENC, 0, TRAIN>(a, s);
+        case 2: return launch_cfg<PREC, 2, RG, ACT, BIGENC, 0, TRAIN>(a, s);
+        case 4: return launch_cfg<PREC, 4, RG, ACT, BIGENC, 0, TRAIN>(a, s);
+        case 8: return launch_cfg<PREC, 8, RG, ACT, BIGENC, 0, TRAIN>(a, s);
     }
     return fail(NERFX_E_ARG, "unsupported tile count %d", wt);
 }
@@ -588,12 +638,12 @@ static int launch_fixed_depth(int activ, int hd, const MlpArgs& a, hipStream_t s
     return fail(NERFX_E_ARG, "unknown activation %d", activ);
 }
 
-template <int PREC, class RG, bool BIGENC>
+template <int PREC, class RG, bool BIGENC, bool TRAIN = false>
 static int launch_activation(int activ, int wt, const MlpArgs& a, hipStream_t s) {
     switch (activ) {
-        case NERFX_ACT_RELU: return launch_width<PREC, RG, NERFX_ACT_RELU, BIGENC>(wt, a, s);
-        case NERFX_ACT_LEAKY_RELU: return launch_width<PREC, RG, NERFX_ACT_LEAKY_RELU, BIGENC>(wt, a, s);
-        case NERFX_ACT_SILU: return launch_width<PREC, RG, NERFX_ACT_SILU, BIGENC>(wt, a, s);
+        case NERFX_ACT_RELU: return launch_width<PREC, RG, NERFX_ACT_RELU, BIGENC, TRAIN>(wt, a, s);
+        case NERFX_ACT_LEAKY_RELU: return launch_width<PREC, RG, NERFX_ACT_LEAKY_RELU, BIGENC, TRAIN>(wt, a, s);
+        case NERFX_ACT_SILU: return launch_width<PREC, RG, NERFX_ACT_SILU, BIGENC, TRAIN>(wt, a, s);
     }
     return fail(NERFX_E_ARG, "unknown activation %d", activ);
 }

@@ -7,6 +7,8 @@
 
 namespace nerfx {
 
+int wgrad_tasks_create(nerfx_model* m);             // mlp_wgrad.hip
+
 int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
     NERFX_REQUIRE(d.width >= 16 && d.width <= 256 && d.width % 16 == 0,
                   "width %d unsupported (16..256, multiple of 16)", d.width);
@@ -50,6 +52,31 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
         if (li == 2 * p.hd - 1) p.trunk_units = unit;
     }
     p.total_units = unit;
+    // backward chain
+    p.n_bwd = 2 * p.hd + 2;
+    unit = 0;
+    for (int j = 0; j < p.n_bwd; ++j) {
+        const int src = 2 * p.hd + 2 - j;                           // rgb.2, rgb.0, features, trunk last .. 1
+        const LayerPlan& F = p.layer[src];
+        LayerPlan& L = p.bwd[j];
+        L = LayerPlan{};
+        L.n_tiles = F.chain_tiles; L.out_dim = F.chain_dim;
+        L.chain_tiles = F.n_tiles; L.chain_dim = F.out_dim;
+        L.transposed = 1; L.src_layer = src; L.src_ld = F.in_dim; L.src_col0 = F.enc_cols;
+        L.group = group_tiles(prec, L.n_tiles);
+        L.chain_seg = pad_to_piece(L.chain_tiles * units_per_tile(prec) * L.group);
+        L.unit0 = unit;
+        unit += units_of(L);
+    }
+    p.bwd_units = unit;
+    // tape rows
+    int row = 0;
+    p.tape_ex_row = row; row += ex_units * slots_per_unit(prec);
+    p.tape_ed_row = row; row += ed_units * slots_per_unit(prec);
+    for (int li = 0; li < p.n_layers - 1; ++li) { p.tape_z_row[li] = row; row += 32 * p.layer[li].n_tiles; }
+    p.tape_go_row = p.tape_z_row[p.n_layers - 1] = row; row += 4;
+    p.tape_gs_row = row; row += 4;
+    p.tape_rows = row;
     p.sigw_off = p.n_layers * BIAS_STRIDE;
     p.sigb_off = p.sigw_off + BIAS_STRIDE;
     auto table_floats = [](int kind, int n) { return ((kind == NERFX_ENC_POSITIONAL ? n : 3 * n) + 3) / 4 * 4; };
@@ -97,7 +124,12 @@ __global__ __launch_bounds__(256) void pack_layer_kernel(const float* __restrict
                 const int f = chain_unit_feature(PREC, ku, h, e);
                 col = f < L.chain_dim ? L.enc_cols + f : -1;
             }
-            v[e] = (live && row < L.out_dim && col >= 0) ? W[(int64_t)row * L.in_dim + col] : 0.0f;
+            if (L.transposed) {
+                const int f = chain_unit_feature(PREC, ku, h, e);
+                v[e] = (live && row < L.out_dim && f < L.chain_dim) ? W[(int64_t)f * L.src_ld + L.src_col0 + row] : 0.0f;
+            } else {
+                v[e] = (live && row < L.out_dim && col >= 0) ? W[(int64_t)row * L.in_dim + col] : 0.0f;
+            }
         }
         char* dst = (char*)stream + (L.unit0 + unit) * UNIT_BYTES + lane * 16;
         if (PREC == NERFX_PREC_BF16) {
@@ -132,15 +164,17 @@ static int pack_all(nerfx_model* m, const float* const* tensors, hipStream_t str
     for (int i = 0; i < m->n_tensors; ++i) NERFX_REQUIRE(tensors[i] != nullptr, "tensor %d is NULL", i);
     for (int prec = 0; prec < 2; ++prec) {
         const ModelPlan& p = m->plan[prec];
-        for (int li = 0; li < p.n_layers; ++li) {
-            const LayerPlan& L = p.layer[li];
+        for (int li = 0; li < p.n_layers + p.n_bwd; ++li) {
+            const bool bwd = li >= p.n_layers;
+            const LayerPlan& L = bwd ? p.bwd[li - p.n_layers] : p.layer[li];
+            void* dst = bwd ? m->stream_bwd_dev[prec] : m->stream_dev[prec];
             const int64_t slices = (int64_t)units_of(L) * 64;
             const int grid = (int)std::min<int64_t>((slices + 255) / 256, 4096);
-            const float* W = tensors[tensor_index(p, li, false)];
+            const float* W = tensors[tensor_index(p, bwd ? L.src_layer : li, false)];
             if (prec == NERFX_PREC_BF16)
-                hipLaunchKernelGGL(pack_layer_kernel<NERFX_PREC_BF16>, dim3(grid), dim3(256), 0, stream, W, L, m->stream_dev[prec]);
+                hipLaunchKernelGGL(pack_layer_kernel<NERFX_PREC_BF16>, dim3(grid), dim3(256), 0, stream, W, L, dst);
             else
-                hipLaunchKernelGGL(pack_layer_kernel<NERFX_PREC_FP32>, dim3(grid), dim3(256), 0, stream, W, L, m->stream_dev[prec]);
+                hipLaunchKernelGGL(pack_layer_kernel<NERFX_PREC_FP32>, dim3(grid), dim3(256), 0, stream, W, L, dst);
         }
     }
     auto vec = [&](const float* src, int n, int cap, int off) {
@@ -176,11 +210,14 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
     hipError_t e = hipGetDevice(&m->device);
     for (int prec = 0; prec < 2 && e == hipSuccess; ++prec)
         e = hipMalloc(&m->stream_dev[prec], (size_t)m->plan[prec].total_units * UNIT_BYTES);
+    for (int prec = 0; prec < 2 && e == hipSuccess; ++prec)
+        e = hipMalloc(&m->stream_bwd_dev[prec], (size_t)m->plan[prec].bwd_units * UNIT_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&m->const_dev, (size_t)m->plan[0].const_floats * sizeof(float));
     if (e != hipSuccess) {
         nerfx_model_destroy(m);
         return fail(e == hipErrorOutOfMemory ? NERFX_E_NOMEM : NERFX_E_HIP, "model allocation failed: %s", hipGetErrorString(e));
     }
+    if (int rc = wgrad_tasks_create(m)) { nerfx_model_destroy(m); return rc; }
     if (int rc = pack_all(m, tensors, (hipStream_t)stream)) { nerfx_model_destroy(m); return rc; }
     *out = m;
     return 0;
@@ -196,6 +233,10 @@ extern "C" void nerfx_model_destroy(nerfx_model_t* m) {
     if (!m) return;
     for (int prec = 0; prec < 2; ++prec)
         if (m->stream_dev[prec]) (void)hipFree(m->stream_dev[prec]);
+    for (int prec = 0; prec < 2; ++prec)
+        if (m->stream_bwd_dev[prec]) (void)hipFree(m->stream_bwd_dev[prec]);
+    for (int prec = 0; prec < 2; ++prec)
+        if (m->wtasks_dev[prec]) (void)hipFree(m->wtasks_dev[prec]);
     if (m->const_dev) (void)hipFree(m->const_dev);
     delete m;
 }

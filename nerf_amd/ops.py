@@ -334,13 +334,107 @@ def _wants_grad(module) -> bool:
     return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
 
 
+class _FieldFunction(torch.autograd.Function):
+    """The radiance field with its HIP backward: forward records the tape in a workspace,
+    backward turns (d sigma, d rgb) into one gradient per Linear parameter.  Positions,
+    directions and t carry no gradient (inputs of the reference's training step)."""
+
+    @staticmethod
+    def forward(ctx, handle, prec, p0, p1, t, *params):
+        dev = p0.device
+        if t is None:
+            M, shape_s, shape_c = p0.shape[0], (p0.shape[0],), (p0.shape[0], 3)
+        else:
+            M, shape_s, shape_c = t.numel(), tuple(t.shape), (*t.shape, 3)
+        sigma = torch.empty(shape_s, device=dev)
+        rgb = torch.empty(shape_c, device=dev)
+        ws_bytes = lib.nerfx_mlp_train_workspace_bytes(handle.ptr, prec, M)
+        if ws_bytes < 0:
+            raise _lib.NerfxError("nerfx_mlp_train_workspace_bytes rejected its arguments")
+        ws = torch.empty((max(ws_bytes, 1),), device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            if t is None:
+                check(lib.nerfx_mlp_fwd_train_points(handle.ptr, prec, _p(p0), _p(p1), M, _p(sigma), _p(rgb),
+                                                     _p(ws), ws_bytes, _stream()))
+            else:
+                check(lib.nerfx_mlp_fwd_train_rays(handle.ptr, prec, _p(p0), _p(p1), _p(t), t.shape[0], t.shape[1],
+                                                   _p(sigma), _p(rgb), _p(ws), ws_bytes, _stream()))
+        ctx.handle, ctx.prec, ctx.M, ctx.ws, ctx.ws_bytes = handle, prec, M, ws, ws_bytes
+        ctx.param_meta = [(tuple(p.shape), p.requires_grad) for p in params]
+        ctx.save_for_backward(sigma, rgb)
+        return sigma, rgb
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb):
+        sigma, rgb = ctx.saved_tensors
+        dev = sigma.device
+        g_sigma = torch.zeros_like(sigma) if g_sigma is None else _dev(g_sigma, "g_sigma")
+        g_rgb = torch.zeros_like(rgb) if g_rgb is None else _dev(g_rgb, "g_rgb")
+        grads = [torch.empty(shape, device=dev) if need else None for shape, need in ctx.param_meta]
+        slots = [None, None] + grads                                 # the two encoder tables come first
+        arr = (C.c_void_p * len(slots))(*[None if g is None else g.data_ptr() for g in slots])
+        if ctx.M > 0:
+            with torch.cuda.device(dev):
+                check(lib.nerfx_mlp_bwd(ctx.handle.ptr, ctx.prec, ctx.M, _p(sigma), _p(rgb), _p(g_sigma), _p(g_rgb),
+                                        _p(ctx.ws), ctx.ws_bytes, arr, len(slots), _stream()))
+        else:
+            grads = [None if g is None else g.zero_() for g in grads]
+        ctx.ws = None
+        return (None, None, None, None, None, *grads)
+
+
+class _CompositeFunction(torch.autograd.Function):
+    """raymarch_volume + depth (reference renderer.py:50-57, :203) with the K3b backward."""
+
+    @staticmethod
+    def forward(ctx, sigma, rgb, t, rd):
+        w, rgb_map, depth = composite_fwd(sigma, rgb, t, rd)
+        ctx.save_for_backward(sigma, rgb, t, rd)
+        return w, rgb_map, depth
+
+    @staticmethod
+    def backward(ctx, g_w, g_rgb_map, g_depth):
+        sigma, rgb, t, rd = ctx.saved_tensors
+        g_sigma, g_rgb = composite_bwd(sigma, rgb, t, rd, None, g_rgb_map, g_depth, g_w)
+        return g_sigma, g_rgb, None, None
+
+
+def _field_with_grad(module, p0, p1, t):
+    handle = handle_for(module)
+    params = [p for p in handle._sources[2:]]
+    return _FieldFunction.apply(handle, precision(), p0, p1, t, *params)
+
+
 def field_forward(module, rx: Tensor, rd: Tensor):
     """NeRF.forward: sigma (M,), rgb (..., 3)."""
     if _wants_grad(module):
-        raise NotImplementedError("gradients through NeRF.forward are not built yet: call under torch.no_grad()")
-    sigma, rgb = mlp_points(handle_for(module), rx, rd)
+        x, d = _dev(rx, "rx").reshape(-1, 3), _dev(rd, "rd").reshape(-1, 3)
+        assert x.shape == d.shape, "positions and directions must pair up"
+        sigma, rgb = _field_with_grad(module, x, d, None)
+    else:
+        sigma, rgb = mlp_points(handle_for(module), rx, rd)
     return sigma, rgb.reshape(*rx.shape[:-1], 3)
 
 
 def render_train(coarse, fine, ro, rd, tn, tf, nc, nf, u_c, u_f):
-    raise NotImplementedError("render_volume(train=True) needs the MLP backward kernels, which are not built yet")
+    """render_volume(train=True): the coarse pass and the sample positions are graph-free
+    (reference renderer.py:133-135); gradients reach `fine` through its MLP and the compositor."""
+    ro, rd = _dev(ro, "ro"), _dev(rd, "rd")
+    u_c = None if u_c is None else _dev(u_c, "u_c")
+    u_f = None if u_f is None else _dev(u_f, "u_f")
+    with torch.no_grad():
+        t = sample_encode(ro, rd, tn, tf, nc, u_c, want_rx=False)["t"]
+        if nf > 0:
+            sigma_c, _ = mlp_rays(handle_for(coarse), ro, rd, t, density_only=True)
+            w_c, _, _ = composite_fwd(sigma_c, None, t, rd, want_depth=False)
+            t = pdf_sample(t, w_c, nf, u_f)
+    if nf > 0:
+        fine.requires_grad(True)                                    # reference renderer.py:137
+    if _wants_grad(fine):
+        sigma, rgb = _field_with_grad(fine, ro, rd, t)
+        w, rgb_map, depth = _CompositeFunction.apply(sigma, rgb, t, rd)
+    else:
+        with torch.no_grad():
+            sigma, rgb = mlp_rays(handle_for(fine), ro, rd, t)
+            w, rgb_map, depth = composite_fwd(sigma, rgb, t, rd)
+    return t, w, depth, rgb_map
