@@ -50,6 +50,65 @@ def cpu_baseline(model, tn, tf, nc, nf):
                       f"{best:.2f} s"}
 
 
+FLOP_TRAIN_PER_RAY = 267_517_952      # coarse 64 x density + fine 128 x (forward + wgrad + dgrad)
+
+
+def bench_train(args, model, bvr, dev, rank, world, dist):
+    """A step = one optimisation step on 4,096 rays per GPU exactly as nerf_amd.train.step runs it
+    (render train=True, perturb on, MSE, backward, gradient all-reduce for N > 1, Adam, the
+    per-step loss.item() of reference train.py:94), batches resident in HBM."""
+    from nerf_amd.distributed import average_gradients, broadcast_parameters
+    B = 4096
+    broadcast_parameters(model)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    C, ro, rd = (torch.rand(B, 3, device=dev, generator=g) for _ in range(3))
+    optim = torch.optim.Adam(model.parameters(), lr=5e-4, eps=1e-4 if args.prec == "bf16" else 1e-8)
+    scaler = torch.amp.GradScaler("cuda", enabled=args.prec == "bf16")
+    criterion = torch.nn.MSELoss()
+
+    def step():
+        *_, C_ = bvr.render_volume(model, model, ro, rd, perturb=True, train=True)
+        loss = criterion(C_, C)
+        scaler.scale(loss).backward()
+        average_gradients(model)
+        scaler.unscale_(optim)
+        scaler.step(optim)
+        scaler.update()
+        optim.zero_grad(set_to_none=True)
+        return loss.item()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.destroy_process_group()
+    dt = t_max.item()
+    if rank == 0:
+        rate = world * B * args.steps / dt
+        achieved = rate / world * FLOP_TRAIN_PER_RAY / 1e12
+        print(json.dumps({
+            "metric": "rays/sec (training step, coarse64+fine64)", "value": rate, "unit": "rays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+            "config": {"workload": "4,096-ray optimisation step per GPU, NeRF(PE(3,6),PE(3,6),256,4), BVR(2,6,64c+64f), "
+                                   "perturb on, MSELoss, Adam, GradScaler with bf16", "parallelism": f"data-parallel x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "whole step", "achieved": achieved, "peak": PEAK_TFLOPS[args.prec],
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.prec], "traffic": None},
+            "final_loss": loss}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +118,8 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="rays per render_volume call")
     ap.add_argument("--size", type=int, default=800, help="frame is size x size")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--mode", choices=("render", "train"), default="render",
+                    help="render: the headline metric; train: 4,096-ray optimisation steps (secondary)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,6 +146,8 @@ def main():
     out = torch.zeros(n_rays, 4, device=dev)                 # rgb | depth, stays on the device
     gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
     ops.set_precision(args.prec)
+    if args.mode == "train":
+        return bench_train(args, model, bvr, dev, rank, world, dist)
 
     def step():
         for s in range(0, n_rays, args.batch):

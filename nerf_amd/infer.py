@@ -26,6 +26,12 @@ def infer(coarse: NeRF, fine: NeRF, raymarcher: BVR, ro: Tensor, rd: Tensor, H: 
         e = min(s + batch_size, n)
         *_, D, C = raymarcher.render_volume(coarse, fine, ro[s:e], rd[s:e], train=False)
         depth[s:e], rgb[s:e] = D, C
+    return postprocess(depth, rgb, H, W)
+
+
+def postprocess(depth: Tensor, rgb: Tensor, H: int, W: int):
+    """Per-ray depth (H*W,) and rgb (H*W, 3) -> the two (H, W, 3) CPU frames in [0, 255]
+    (reference infer.py:58-68), computed on the device the inputs live on."""
     depth = depth.view(H, W, 1).repeat((1, 1, 3)).nan_to_num()
     depth = depth - depth.min()
     depth = depth / (depth.max() + 1e-10)

@@ -8,6 +8,8 @@ operations of one optimisation step (train.py:75-86):
 The render and its backward run on the HIP kernels; `autocast` selects the bf16 MFMA
 contractions (the loss scale of a GradScaler then only rescales fp32 gradients, which
 is harmless).  Optimizer, scaler, criterion and scheduler are the caller's objects.
+When torch.distributed is initialised with more than one rank, every rank runs this loop on
+its own batches and the gradients are averaged (one flat all-reduce) before `unscale_`.
 """
 from typing import Callable, List, Optional, Tuple
 
@@ -23,6 +25,7 @@ from .core.model import NeRF
 from .core.renderer import BoundedVolumeRaymarcher as BVR
 from .core.scheduler import Scheduler
 from .data.utils import loaders
+from .distributed import average_gradients
 from .utils.history import History
 from .utils.pbar import tqdm
 
@@ -50,6 +53,7 @@ def step(epoch: int, nerf: NeRF, raymarcher: BVR, optim: Optimizer, scheduler: S
 
             if train:
                 scaler.scale(loss).backward()
+                average_gradients(nerf)          # data parallel: no-op in a single process
                 scaler.unscale_(optim)
                 if GRAD_NORM_CLIP > 0.:
                     clip_grad_norm_(nerf.parameters(), GRAD_NORM_CLIP)
