@@ -31,6 +31,19 @@ FLOP_DENSITY = 433_664       # algorithmic FLOP per sample, trunk + density head
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
 
 
+def recorded_traffic(prec):
+    """HBM bytes per MLP launch from the committed PMC summary of this same command
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH doubled as gfx950 requires), or None."""
+    path = os.path.join(ROOT, "profiles", f"r1_bench_{prec}_pmc_hbm.json")
+    try:
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+        k = next(v for name, v in kernels.items() if "mlp_fwd_kernel" in name)
+        return (k["fetch_corrected_KB"] + k["WRITE_SIZE_KB"]) * 1e3
+    except (OSError, KeyError, StopIteration, ValueError):
+        return None
+
+
 def cpu_baseline(model, tn, tf, nc, nf):
     from oracle import nerf_oracle as O
     params = {k: v.detach().cpu() for k, v in model.named_parameters()}
@@ -197,7 +210,7 @@ def main():
                        "rays_per_step_per_gpu": n_rays, "parallelism": f"frame-sharded x{world}"},
             "roofline": {"bound": "mfma", "kernel": "mlp_fwd_kernel", "achieved": achieved,
                          "peak": PEAK_TFLOPS[args.prec], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.prec],
-                         "traffic": None, "launches": mlp_launches,
+                         "traffic": recorded_traffic(args.prec), "launches": mlp_launches,
                          "avg_launch_ms": stage_ms["mlp"] / mlp_launches,
                          "flop_per_launch": mlp_flop / mlp_launches},
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
