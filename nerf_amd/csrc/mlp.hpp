@@ -41,26 +41,32 @@ constexpr int MAX_TABLE = 1024;                 // floats per encoder table
 __host__ __device__ constexpr int slots_per_unit(int prec) { return prec == NERFX_PREC_BF16 ? 16 : 8; }
 __host__ __device__ constexpr int units_per_tile(int prec) { return prec == NERFX_PREC_BF16 ? 2 : 4; }
 
-// Encoder slot order used inside the kernels: slot 2p = sin(angle p), 2p+1 =
-// cos(angle p); a positional encoder then appends the 3 raw coordinates.
-// Returns the column of the REFERENCE layout (features.py:32-36, :52) held by
+// Encoder slot order used inside the kernels.  A positional encoder first has its 3 raw
+// coordinates (and one zero) in slots 0..3 -- a fixed place whatever the number of
+// frequencies -- then, for both kinds, sin/cos pairs: pair-slot k = slot / 2 holds
+// sin (even slot) and cos (odd slot) of the angle of pair k - raw_slots / 2.
+// enc_slot_col returns the column of the REFERENCE layout (features.py:32-36, :52) held by
 // `slot`, or -1 for padding.
+__host__ __device__ constexpr int enc_raw_slots(int kind) { return kind == NERFX_ENC_POSITIONAL ? 4 : 0; }
 __host__ __device__ inline int enc_slot_col(int kind, int n, int slot) {
+    const int R = enc_raw_slots(kind);
+    if (slot < R) return slot < 3 ? slot : -1;
     const int P = kind == NERFX_ENC_POSITIONAL ? 3 * n : n;
-    const int q = slot >> 1, which = slot & 1;
-    if (q < P) {
-        if (kind == NERFX_ENC_POSITIONAL) { const int f = q / 3, c = q - 3 * f; return 3 + 6 * f + 3 * which + c; }
-        return which * n + q;
-    }
-    const int c = slot - 2 * P;
-    return (kind == NERFX_ENC_POSITIONAL && c < 3) ? c : -1;
+    const int q = (slot - R) >> 1, which = (slot - R) & 1;
+    if (q >= P) return -1;
+    if (kind == NERFX_ENC_POSITIONAL) { const int f = q / 3, c = q - 3 * f; return 3 + 6 * f + 3 * which + c; }
+    return which * n + q;
 }
 // k-units an encoder occupies (padded with zero weights to a multiple of ENC_BLOCK).
 __host__ __device__ inline int enc_units(int kind, int n, int prec) {
-    const int slots = (kind == NERFX_ENC_POSITIONAL ? 6 * n + 3 : 2 * n);
+    const int slots = enc_raw_slots(kind) + (kind == NERFX_ENC_POSITIONAL ? 6 * n : 2 * n);
     const int units = (slots + slots_per_unit(prec) - 1) / slots_per_unit(prec);
     return (units + ENC_BLOCK - 1) / ENC_BLOCK * ENC_BLOCK;
 }
+// Entries of an encoder's pair-coefficient table (one float4 per pair-slot, covering the
+// padded units of either precision): angle of pair-slot k = c[k] . v' with v' = v (positional,
+// c = frequency on one axis) or 2 pi v (Fourier, c = b row).
+__host__ __device__ inline int enc_pair_slots(int kind, int n) { return enc_units(kind, n, NERFX_PREC_BF16) * 8; }
 // Encoder slot supplied by lane half h as element e of k-unit u.
 __host__ __device__ inline int enc_unit_slot(int prec, int u, int h, int e) {
     const int spu = slots_per_unit(prec);

@@ -199,6 +199,11 @@ template <> struct Prec<NERFX_PREC_BF16> {
         c = __builtin_amdgcn_cosf(r);
     }
     static __device__ __forceinline__ float expneg(float x) { return __expf(-x); }
+    // output activations with hardware exp / log / rcp: their ~1e-6 error is far inside bf16's
+    static __device__ __forceinline__ float softplus(float x) { return __logf(1.0f + __expf(-fabsf(x))) + fmaxf(x, 0.0f); }
+    static __device__ __forceinline__ float widened_sigmoid(float x) {
+        return fmaf(1.002f, __frcp_rn(1.0f + __expf(-x)), -0.001f);
+    }
 };
 
 template <> struct Prec<NERFX_PREC_FP32> {
@@ -221,28 +226,29 @@ template <> struct Prec<NERFX_PREC_FP32> {
     }
     static __device__ __forceinline__ void sincos_pair(float angle, float& s, float& c) { sincosf(angle, &s, &c); }
     static __device__ __forceinline__ float expneg(float x) { return expf(-x); }
+    // activations.py:33-35 and :18-20, evaluated as the reference writes them
+    static __device__ __forceinline__ float softplus(float x) { return log1pf(expf(-fabsf(x))) + (x >= 0.0f ? x : 0.0f); }
+    static __device__ __forceinline__ float widened_sigmoid(float x) { return 0.5f * (1.0f + 1.002f * tanhf(0.5f * x)); }
 };
 
-// B operand of encoder k-unit u for this lane's point (vx, vy, vz): see enc_unit_slot().
+// B operand of encoder k-unit u for this lane's point: slots per enc_unit_slot() / enc_slot_col().
+// `table` is the encoder's pair-coefficient table (float4 per pair-slot, LDS); (sx, sy, sz) is
+// the point as the angles want it (v for positional, 2 pi v for Fourier: features.py:34, :51);
+// a positional encoder's unit 0 starts with the raw coordinates in lane half 0.
 template <int PREC>
-__device__ __forceinline__ typename Prec<PREC>::Frag encode_unit(int kind, int n, lds_floats_t table, int u,
-                                                                 int h, float vx, float vy, float vz) {
+__device__ __forceinline__ typename Prec<PREC>::Frag encode_unit(lds_floats_t table, bool positional, int u, int h,
+                                                                 float sx, float sy, float sz) {
     using P = Prec<PREC>;
     constexpr int SPUH = P::SPUH;
-    const int pairs = enc_pairs(kind, n);
+    const lds_floats_t c0 = table + 4 * ((SPUH * u) + (SPUH / 2) * h);       // this lane's first pair-slot
     float v[SPUH];
 #pragma unroll
     for (int i = 0; i < SPUH / 2; ++i) {
-        const int q = SPUH * u + (SPUH / 2) * h + i;         // pair index = slot / 2
-        if (q < pairs) {
-            P::sincos_pair(enc_angle(kind, table, q, vx, vy, vz), v[2 * i], v[2 * i + 1]);
-        } else {
-            const int c = 2 * (q - pairs);                   // raw coordinates follow the pairs
-            const bool pe = kind == NERFX_ENC_POSITIONAL;
-            v[2 * i] = (pe && c < 3) ? (c == 0 ? vx : (c == 1 ? vy : vz)) : 0.0f;
-            v[2 * i + 1] = (pe && c + 1 < 3) ? (c + 1 == 1 ? vy : vz) : 0.0f;
-        }
+        const f32x4 c = NERFX_LDS_VEC(f32x4, c0 + 4 * i);
+        const float angle = fmaf(sz, c[2], fmaf(sy, c[1], __fmul_rn(sx, c[0])));
+        P::sincos_pair(angle, v[2 * i], v[2 * i + 1]);
     }
+    if (positional && u == 0 && h == 0) { v[0] = sx; v[1] = sy; v[2] = sz; v[3] = 0.0f; }
     return P::from_floats(v);
 }
 
@@ -251,20 +257,24 @@ __device__ __forceinline__ typename Prec<PREC>::Frag encode_unit(int kind, int n
 template <int PREC>
 struct Encoding {
     typename Prec<PREC>::Frag cached[ENC_BLOCK];
-    int kind, n, units;
+    int units;
+    bool positional;
     lds_floats_t table;
-    float vx, vy, vz;
+    float sx, sy, sz;
     int h;
     template <bool BIGENC>
-    __device__ __forceinline__ void prepare(int k, int nn, int nu, lds_floats_t tb, int hh, float x, float y, float z) {
-        kind = k; n = nn; units = nu; table = tb; h = hh; vx = x; vy = y; vz = z;
+    __device__ __forceinline__ void prepare(int kind, int nu, lds_floats_t tb, int hh, float x, float y, float z) {
+        positional = kind == NERFX_ENC_POSITIONAL;
+        const float scale = positional ? 1.0f : 6.283185307179586f;
+        units = nu; table = tb; h = hh;
+        sx = __fmul_rn(scale, x); sy = __fmul_rn(scale, y); sz = __fmul_rn(scale, z);
         if (!BIGENC) {
 #pragma unroll
-            for (int u = 0; u < ENC_BLOCK; ++u) cached[u] = encode_unit<PREC>(kind, n, table, u, h, vx, vy, vz);
+            for (int u = 0; u < ENC_BLOCK; ++u) cached[u] = encode_unit<PREC>(table, positional, u, h, sx, sy, sz);
         }
     }
     __device__ __forceinline__ typename Prec<PREC>::Frag eval(int u) const {
-        return encode_unit<PREC>(kind, n, table, u, h, vx, vy, vz);
+        return encode_unit<PREC>(table, positional, u, h, sx, sy, sz);
     }
 };
 
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         // in the wave's LDS stash (the MFMA blocks read them from there); the others keep them
         // in registers, (re)built right before each consuming layer.
         Encoding<PREC> enc;
-        enc.template prepare<BIGENC>(a.ex_kind, a.ex_n, a.ex_units, cst + a.tabx_off, h, px, py, pz);
+        enc.template prepare<BIGENC>(a.ex_kind, a.ex_units, cst + a.tabx_off, h, px, py, pz);
         uint32_t stash = 0;
         if constexpr (STASH) {
 #pragma unroll
@@ -539,7 +549,7 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         auto refresh = [&](int li) {                               // register-resident encodings only
             if (!STASH && li == skip) {
                 st.mark(ST_EPILOGUE);
-                enc.template prepare<BIGENC>(a.ex_kind, a.ex_n, a.ex_units, cst + a.tabx_off, h, px, py, pz);
+                enc.template prepare<BIGENC>(a.ex_kind, a.ex_units, cst + a.tabx_off, h, px, py, pz);
                 st.mark(ST_ENCODE);
             }
         };
@@ -560,7 +570,7 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         {
             dot += __shfl_xor(dot, 32, 64);
             const float sx = (dot + cst[a.sigb_off]) - 1.0f;
-            float sg = log1pf(expf(-fabsf(sx))) + (sx >= 0.0f ? sx : 0.0f);
+            float sg = P::softplus(sx);
             if (poisoned) sg = __builtin_nanf("");
             if (valid && h == 0) a.sigma[m] = sg;
         }
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
             linear<PREC, RG, -1, BIGENC, WT, WT, false, false, TRAIN>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, st, nullptr, 0, zt, a.tape_z_row[li]);
             ++li;
             // ---- rgb.0 on [phi_d | features] (model.py:53, :76): A -> B ---------------------
-            { st.mark(ST_EPILOGUE); enc.template prepare<BIGENC>(a.ed_kind, a.ed_n, a.ed_units, cst + a.tabd_off, h, dx, dy, dz); st.mark(ST_ENCODE); }
+            { st.mark(ST_EPILOGUE); enc.template prepare<BIGENC>(a.ed_kind, a.ed_units, cst + a.tabd_off, h, dx, dy, dz); st.mark(ST_ENCODE); }
             linear<PREC, RG, ACT, BIGENC, RT, WT, false, false, TRAIN>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw, st, nullptr, 0, zt, a.tape_z_row[li], a.tape_ed_row);
             ++li;
             // ---- rgb.2 + widened sigmoid (model.py:54, activations.py:18-20) ----------------
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
                 // rows 0..2 of the output tile sit in accumulator registers 0..2 of lane half 0
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    float v = 0.5f * (1.0f + 1.002f * tanhf(0.5f * out[c]));
+                    float v = P::widened_sigmoid(out[c]);
                     if (poisoned) v = __builtin_nanf("");
                     a.rgb[3 * (size_t)m + c] = v;
                 }

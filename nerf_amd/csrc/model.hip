@@ -79,7 +79,7 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
     p.tape_rows = row;
     p.sigw_off = p.n_layers * BIAS_STRIDE;
     p.sigb_off = p.sigw_off + BIAS_STRIDE;
-    auto table_floats = [](int kind, int n) { return ((kind == NERFX_ENC_POSITIONAL ? n : 3 * n) + 3) / 4 * 4; };
+    auto table_floats = [](int kind, int n) { return 4 * enc_pair_slots(kind, n); };
     p.tabx_off = p.sigb_off + 4;
     p.tabd_off = p.tabx_off + table_floats(d.enc_x_kind, d.enc_x_n);
     p.const_floats = p.tabd_off + table_floats(d.enc_d_kind, d.enc_d_n);
@@ -148,6 +148,25 @@ __global__ __launch_bounds__(256) void pack_vector_kernel(const float* __restric
     for (int i = blockIdx.x * 256 + threadIdx.x; i < cap; i += gridDim.x * 256) dst[i] = i < n ? src[i] : 0.0f;
 }
 
+// Pair-coefficient table of one encoder (see enc_pair_slots): entry k = (cx, cy, cz, 0).
+__global__ __launch_bounds__(256) void pack_pair_table_kernel(const float* __restrict__ src, int kind, int n, int entries,
+                                                              float* __restrict__ dst) {
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < entries; k += gridDim.x * 256) {
+        const int q = k - enc_raw_slots(kind) / 2;
+        float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (q >= 0 && q < enc_pairs(kind, n)) {
+            if (kind == NERFX_ENC_POSITIONAL) {
+                const int f = q / 3, axis = q - 3 * f;
+                const float w = src[f];
+                c = make_float4(axis == 0 ? w : 0.0f, axis == 1 ? w : 0.0f, axis == 2 ? w : 0.0f, 0.0f);
+            } else {
+                c = make_float4(src[3 * q], src[3 * q + 1], src[3 * q + 2], 0.0f);
+            }
+        }
+        reinterpret_cast<float4*>(dst)[k] = c;
+    }
+}
+
 static int tensor_index(const ModelPlan& p, int li, bool bias) {
     const int hd = p.hd;
     int base;
@@ -184,8 +203,13 @@ static int pack_all(nerfx_model* m, const float* const* tensors, hipStream_t str
         vec(tensors[tensor_index(p0, li, true)], p0.layer[li].out_dim, BIAS_STRIDE, li * BIAS_STRIDE);
     vec(tensors[2 + 4 * p0.hd], d.width, BIAS_STRIDE, p0.sigw_off);
     vec(tensors[2 + 4 * p0.hd + 1], 1, 4, p0.sigb_off);
-    vec(tensors[0], d.enc_x_kind == NERFX_ENC_POSITIONAL ? d.enc_x_n : 3 * d.enc_x_n, p0.tabd_off - p0.tabx_off, p0.tabx_off);
-    vec(tensors[1], d.enc_d_kind == NERFX_ENC_POSITIONAL ? d.enc_d_n : 3 * d.enc_d_n, p0.const_floats - p0.tabd_off, p0.tabd_off);
+    auto table = [&](const float* src, int kind, int n, int off) {
+        const int entries = enc_pair_slots(kind, n);
+        hipLaunchKernelGGL(pack_pair_table_kernel, dim3((entries + 255) / 256), dim3(256), 0, stream, src, kind, n, entries,
+                           m->const_dev + off);
+    };
+    table(tensors[0], d.enc_x_kind, d.enc_x_n, p0.tabx_off);
+    table(tensors[1], d.enc_d_kind, d.enc_d_n, p0.tabd_off);
     return launch_status("pack kernels");
 }
 
