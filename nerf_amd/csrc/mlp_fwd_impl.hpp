@@ -167,6 +167,15 @@ template <> struct Prec<NERFX_PREC_BF16> {
     static constexpr int SPUH = 8;                          // elements a lane supplies per k-unit
     static constexpr int UPT = 2;
     using Frag = bf16x8;                                    // one B operand per k-unit
+    // Two floats -> one dword of two bf16 (round to nearest even, NaN stays NaN).  Spelled out
+    // because hipcc converts element by element (one v_cvt_pk per float plus a v_perm per pair).
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        uint32_t r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    }
+    // (the inputs of pack2 must not come straight from an MFMA or a transcendental instruction:
+    // hipcc pads no hazard for an asm consumer -- from_floats therefore converts the plain way)
     static __device__ __forceinline__ Frag from_floats(const float (&v)[8]) {
         Frag f;
 #pragma unroll
@@ -175,10 +184,10 @@ template <> struct Prec<NERFX_PREC_BF16> {
     }
     // accumulator registers 8s..8s+7 of tile `a` -> B operand of chained k-unit 2T+s
     static __device__ __forceinline__ Frag from_acc(const f32x16& a, int s) {
-        Frag f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (__bf16)a[8 * s + e];
-        return f;
+        using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+        const u32x4 p = {pack2(a[8 * s], a[8 * s + 1]), pack2(a[8 * s + 2], a[8 * s + 3]),
+                         pack2(a[8 * s + 4], a[8 * s + 5]), pack2(a[8 * s + 6], a[8 * s + 7])};
+        return __builtin_bit_cast(Frag, p);
     }
     // ReLU on packed bf16: a negative float is a negative int16 (v_pk_max_i16 with 0)
     static constexpr bool PACKED_RELU = true;
@@ -322,6 +331,13 @@ __device__ __forceinline__ void run_units(const WeightRing<RG>& ring, f32x16 (&a
         if (i + D < N) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PREC == NERFX_PREC_BF16) {
+        // the epilogue's asm conversions (pack2) read these accumulators: let the last MFMA finish,
+        // as the hand-scheduled blocks do with their closing nops
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0]));
+#pragma unroll
+        for (int t = 1; t < NG; ++t) asm volatile("" : "+v"(acc[t]));
+    }
 }
 
 // Whether a kernel configuration keeps the positional encoding of x in the LDS stash.
