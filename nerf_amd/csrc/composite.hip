@@ -1,69 +1,112 @@
 // K3 / K3b: alpha compositing along rays, forward and backward.
 //
-// One 64-lane wavefront owns one ray.  Lane l holds EPL consecutive samples
-// (vector loads, fully coalesced per ray); transmittance is an in-lane running
-// product followed by a 6-step cross-lane product scan, and the ray sums are
-// wave reductions.  The kernels are HBM-bound: every input is read once and
-// every output written once.
+// A group of 32 lanes (64 beyond 256 samples) owns one ray.  A lane holds EPL consecutive
+// samples (128-bit loads and stores when rows are whole 16-byte slices, as for 128 samples);
+// transmittance is an in-lane running product followed by a cross-lane product scan inside the
+// group, and the ray sums are group reductions.  The kernels are HBM-bound: every input is
+// read once and every output written once.
 #include "common.hpp"
 
 namespace nerfx {
 
-constexpr int K3_WAVES = 4;                      // waves (= rays in flight) per workgroup
+constexpr int K3_WAVES = 4;                      // waves per workgroup
 constexpr float K3_EPS = 1e-10f;                 // renderer.py:48
 
-__device__ __forceinline__ float wave_sum(float v) {
+// A ray is owned by a GROUP of LPR consecutive lanes (LPR = 32: two rays per wavefront, 64: one);
+// all cross-lane steps stay inside the group.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, LPR);
     return v;
 }
-// Exclusive product scan across the 64 lanes.
-__device__ __forceinline__ float wave_excl_prod(float v, int lane) {
+// Exclusive product scan across the group (gl = lane index inside the group).
+template <int LPR>
+__device__ __forceinline__ float group_excl_prod(float v, int gl) {
     float inc = v;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_up(inc, off, 64);
-        if (lane >= off) inc *= o;
+    for (int off = 1; off < LPR; off <<= 1) {
+        const float o = __shfl_up(inc, off, LPR);
+        if (gl >= off) inc *= o;
     }
-    const float prev = __shfl_up(inc, 1, 64);
-    return lane == 0 ? 1.0f : prev;
+    const float prev = __shfl_up(inc, 1, LPR);
+    return gl == 0 ? 1.0f : prev;
 }
-// Exclusive suffix sum across the 64 lanes (sum over lanes > this one).
-__device__ __forceinline__ float wave_excl_suffix_sum(float v, int lane) {
+// Exclusive suffix sum across the group (sum over lanes after this one).
+template <int LPR>
+__device__ __forceinline__ float group_excl_suffix_sum(float v, int gl) {
     float inc = v;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_down(inc, off, 64);
-        if (lane + off < 64) inc += o;
+    for (int off = 1; off < LPR; off <<= 1) {
+        const float o = __shfl_down(inc, off, LPR);
+        if (gl + off < LPR) inc += o;
     }
-    const float next = __shfl_down(inc, 1, 64);
-    return lane == 63 ? 0.0f : next;
+    const float next = __shfl_down(inc, 1, LPR);
+    return gl == LPR - 1 ? 0.0f : next;
 }
 
-// Loads this lane's EPL samples of one ray and forms delta and alpha.
-template <int EPL>
+// N consecutive floats starting at p[0] (this lane's slice of a row).  `vec` (wave-uniform):
+// every lane's slice is whole and aligned to its own size, so 64/128-bit accesses are legal.
+template <int N>
+__device__ __forceinline__ void load_slice(const float* __restrict__ p, int valid, bool vec, float (&v)[N]) {
+    if (vec && N % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < N / 4; ++k) {
+            const float4 q = reinterpret_cast<const float4*>(p)[k];
+            v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+        }
+    } else if (vec && N % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) {
+            const float2 q = reinterpret_cast<const float2*>(p)[k];
+            v[2 * k] = q.x; v[2 * k + 1] = q.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = k < valid ? p[k] : 0.0f;
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_slice(float* __restrict__ p, int valid, bool vec, const float (&v)[N]) {
+    if (vec && N % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < N / 4; ++k)
+            reinterpret_cast<float4*>(p)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    } else if (vec && N % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) reinterpret_cast<float2*>(p)[k] = make_float2(v[2 * k], v[2 * k + 1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (k < valid) p[k] = v[k];
+    }
+}
+
+// This lane's EPL samples of one ray, with delta and alpha.
+template <int EPL, int LPR>
 struct RaySlice {
     float sigma[EPL], t[EPL], delta[EPL], alpha[EPL], x[EPL];
-    bool live[EPL];
+    int valid;                                    // live samples in this lane's slice
+    bool vec;                                     // whole-row vector access is legal (wave-uniform)
 
     __device__ __forceinline__ void load(const float* __restrict__ sigma_g, const float* __restrict__ t_g,
                                          const float* __restrict__ rd_g, const float* __restrict__ delta_g,
-                                         int64_t ray, int n, int lane) {
+                                         int64_t ray, int n, int gl) {
         const int64_t base = ray * n;
-        const int i0 = lane * EPL;
+        const int i0 = gl * EPL;
+        valid = min(max(n - i0, 0), EPL);
+        vec = n == EPL * LPR;                     // full rows: slices are whole and naturally aligned
+        load_slice<EPL>(sigma_g + base + i0, valid, vec, sigma);
+        if (t_g) load_slice<EPL>(t_g + base + i0, valid, vec, t);
+        else
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            live[e] = i0 + e < n;
-            sigma[e] = live[e] ? sigma_g[base + i0 + e] : 0.0f;
-            t[e] = (live[e] && t_g) ? t_g[base + i0 + e] : 0.0f;
-        }
+            for (int e = 0; e < EPL; ++e) t[e] = 0.0f;
         if (delta_g) {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) delta[e] = live[e] ? delta_g[base + i0 + e] : 0.0f;
+            load_slice<EPL>(delta_g + base + i0, valid, vec, delta);
         } else {
             // ray.py:62-65: forward difference, 1e10 behind the last sample, times |rd|
             const float len = norm3(rd_g[3 * ray], rd_g[3 * ray + 1], rd_g[3 * ray + 2]);
-            const float t_next_lane = __shfl_down(t[0], 1, 64);
+            const float t_next_lane = __shfl_down(t[0], 1, LPR);
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 const float tn = e + 1 < EPL ? t[e + 1 < EPL ? e + 1 : e] : t_next_lane;
@@ -74,105 +117,114 @@ struct RaySlice {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             alpha[e] = 1.0f - expf(-(sigma[e] * delta[e]));           // renderer.py:50
-            x[e] = live[e] ? (1.0f - alpha[e]) + K3_EPS : 1.0f;       // renderer.py:51
+            x[e] = e < valid ? (1.0f - alpha[e]) + K3_EPS : 1.0f;     // renderer.py:51
         }
     }
     // Transmittance in front of each of this lane's samples.
-    __device__ __forceinline__ void transmittance(float (&T)[EPL], int lane) const {
+    __device__ __forceinline__ void transmittance(float (&T)[EPL], int gl) const {
         float run = 1.0f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) run *= x[e];
-        float before = wave_excl_prod(run, lane);
+        float before = group_excl_prod<LPR>(run, gl);
 #pragma unroll
         for (int e = 0; e < EPL; ++e) { T[e] = before; before *= x[e]; }
     }
 };
 
-template <int EPL>
+template <int EPL, int LPR>
 __global__ __launch_bounds__(64 * K3_WAVES) void composite_fwd_kernel(
     const float* __restrict__ sigma, const float* __restrict__ rgb, const float* __restrict__ t,
     const float* __restrict__ rd, const float* __restrict__ delta, int64_t n_rays, int n,
     float* __restrict__ weights, float* __restrict__ rgb_map, float* __restrict__ depth_map) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * K3_WAVES + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * K3_WAVES;
-    for (int64_t ray = wave; ray < n_rays; ray += n_waves) {
-        RaySlice<EPL> s;
-        s.load(sigma, t, rd, delta, ray, n, lane);
+    constexpr int RPW = 64 / LPR;                                   // rays per wavefront
+    const int lane = threadIdx.x & 63, gl = lane % LPR;
+    const int64_t group = ((int64_t)blockIdx.x * K3_WAVES + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const int64_t n_groups = (int64_t)gridDim.x * K3_WAVES * RPW;
+    // whole wavefronts stay in the loop together (the shuffles need every lane of a group)
+    for (int64_t ray0 = group - lane / LPR; ray0 < n_rays; ray0 += n_groups) {
+        const int64_t ray = min(ray0 + lane / LPR, n_rays - 1);
+        const bool mine = ray0 + lane / LPR < n_rays;
+        RaySlice<EPL, LPR> s;
+        s.load(sigma, t, rd, delta, ray, n, gl);
         float T[EPL];
-        s.transmittance(T, lane);
-        float r = 0.f, g = 0.f, b = 0.f, d = 0.f;
-        const int64_t base = ray * n + lane * EPL;
+        s.transmittance(T, gl);
+        const int64_t base = ray * n + gl * EPL;
+        float w[EPL], c[3 * EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            if (!s.live[e]) continue;
-            const float w = s.alpha[e] * T[e];                          // renderer.py:52
-            if (weights) weights[base + e] = w;
-            if (rgb) {
-                r += w * rgb[(base + e) * 3 + 0];
-                g += w * rgb[(base + e) * 3 + 1];
-                b += w * rgb[(base + e) * 3 + 2];
-            }
-            d += w * s.t[e];
+        for (int e = 0; e < EPL; ++e) w[e] = s.alpha[e] * T[e];        // renderer.py:52
+        if (weights && mine) store_slice<EPL>(weights + base, s.valid, s.vec, w);
+        float r = 0.f, g = 0.f, b = 0.f, d = 0.f;
+        if (rgb) {
+            load_slice<3 * EPL>(rgb + base * 3, 3 * s.valid, s.vec, c);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                if (e < s.valid) { r += w[e] * c[3 * e]; g += w[e] * c[3 * e + 1]; b += w[e] * c[3 * e + 2]; }
         }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+            if (e < s.valid) d += w[e] * s.t[e];
         if (rgb_map) {
-            r = wave_sum(r); g = wave_sum(g); b = wave_sum(b);
-            if (lane == 0) { rgb_map[3 * ray] = r; rgb_map[3 * ray + 1] = g; rgb_map[3 * ray + 2] = b; }
+            r = group_sum<LPR>(r); g = group_sum<LPR>(g); b = group_sum<LPR>(b);
+            if (gl == 0 && mine) { rgb_map[3 * ray] = r; rgb_map[3 * ray + 1] = g; rgb_map[3 * ray + 2] = b; }
         }
         if (depth_map) {
-            d = wave_sum(d);
-            if (lane == 0) depth_map[ray] = d;                          // renderer.py:203
+            d = group_sum<LPR>(d);
+            if (gl == 0 && mine) depth_map[ray] = d;                    // renderer.py:203
         }
     }
 }
 
 // dL/dalpha_i = T_i G_i - (sum_{k>i} w_k G_k) / x_i,  G_i = dL/dw_i;
 // dalpha_i/dsigma_i = delta_i (1 - alpha_i);  dL/drgb_ic = w_i g_c.
-template <int EPL>
+template <int EPL, int LPR>
 __global__ __launch_bounds__(64 * K3_WAVES) void composite_bwd_kernel(
     const float* __restrict__ sigma, const float* __restrict__ rgb, const float* __restrict__ t,
     const float* __restrict__ rd, const float* __restrict__ delta, int64_t n_rays, int n,
     const float* __restrict__ g_rgb_map, const float* __restrict__ g_depth,
     const float* __restrict__ g_weights, float* __restrict__ g_sigma, float* __restrict__ g_rgb) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * K3_WAVES + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * K3_WAVES;
-    for (int64_t ray = wave; ray < n_rays; ray += n_waves) {
-        RaySlice<EPL> s;
-        s.load(sigma, t, rd, delta, ray, n, lane);
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, gl = lane % LPR;
+    const int64_t group = ((int64_t)blockIdx.x * K3_WAVES + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const int64_t n_groups = (int64_t)gridDim.x * K3_WAVES * RPW;
+    for (int64_t ray0 = group - lane / LPR; ray0 < n_rays; ray0 += n_groups) {
+        const int64_t ray = min(ray0 + lane / LPR, n_rays - 1);
+        const bool mine = ray0 + lane / LPR < n_rays;
+        RaySlice<EPL, LPR> s;
+        s.load(sigma, t, rd, delta, ray, n, gl);
         float T[EPL];
-        s.transmittance(T, lane);
+        s.transmittance(T, gl);
         const float gr = g_rgb_map ? g_rgb_map[3 * ray] : 0.f, gg = g_rgb_map ? g_rgb_map[3 * ray + 1] : 0.f,
                     gb = g_rgb_map ? g_rgb_map[3 * ray + 2] : 0.f, gd = g_depth ? g_depth[ray] : 0.f;
-        const int64_t base = ray * n + lane * EPL;
-        float w[EPL], G[EPL], wG[EPL];
+        const int64_t base = ray * n + gl * EPL;
+        float w[EPL], G[EPL], wG[EPL], c[3 * EPL], gw[EPL];
+        if (rgb) load_slice<3 * EPL>(rgb + base * 3, 3 * s.valid, s.vec, c);
+        if (g_weights) load_slice<EPL>(g_weights + base, s.valid, s.vec, gw);
         float lane_total = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             w[e] = s.alpha[e] * T[e];
             G[e] = 0.f;
-            if (s.live[e]) {
-                if (rgb) G[e] = gr * rgb[(base + e) * 3] + gg * rgb[(base + e) * 3 + 1] + gb * rgb[(base + e) * 3 + 2];
+            if (e < s.valid) {
+                if (rgb) G[e] = gr * c[3 * e] + gg * c[3 * e + 1] + gb * c[3 * e + 2];
                 G[e] += gd * s.t[e];
-                if (g_weights) G[e] += g_weights[base + e];
+                if (g_weights) G[e] += gw[e];
             }
-            wG[e] = s.live[e] ? w[e] * G[e] : 0.f;
+            wG[e] = e < s.valid ? w[e] * G[e] : 0.f;
             lane_total += wG[e];
         }
-        float after = wave_excl_suffix_sum(lane_total, lane);     // sum over later lanes
+        float after = group_excl_suffix_sum<LPR>(lane_total, gl);   // sum over later lanes
+        float gs[EPL], gc[3 * EPL];
 #pragma unroll
         for (int e = EPL - 1; e >= 0; --e) {
-            if (s.live[e]) {
-                const float g_alpha = T[e] * G[e] - after / s.x[e];
-                // d alpha / d sigma = delta * exp(-sigma delta) = delta * (1 - alpha)
-                g_sigma[base + e] = g_alpha * (s.delta[e] * (1.0f - s.alpha[e]));
-                if (g_rgb) {
-                    g_rgb[(base + e) * 3 + 0] = w[e] * gr;
-                    g_rgb[(base + e) * 3 + 1] = w[e] * gg;
-                    g_rgb[(base + e) * 3 + 2] = w[e] * gb;
-                }
-            }
+            const float g_alpha = T[e] * G[e] - after / s.x[e];
+            // d alpha / d sigma = delta * exp(-sigma delta) = delta * (1 - alpha)
+            gs[e] = g_alpha * (s.delta[e] * (1.0f - s.alpha[e]));
+            gc[3 * e] = w[e] * gr; gc[3 * e + 1] = w[e] * gg; gc[3 * e + 2] = w[e] * gb;
             after += wG[e];
+        }
+        if (mine) {
+            store_slice<EPL>(g_sigma + base, s.valid, s.vec, gs);
+            if (g_rgb) store_slice<3 * EPL>(g_rgb + base * 3, 3 * s.valid, s.vec, gc);
         }
     }
 }
@@ -188,23 +240,29 @@ __global__ __launch_bounds__(256) void segment_lengths_kernel(const float* __res
     }
 }
 
-static int composite_grid(int64_t n_rays) {
-    return (int)std::min<int64_t>((n_rays + K3_WAVES - 1) / K3_WAVES, 256 * 8);
+static int composite_grid(int64_t n_rays, int n) {
+    const int per_block = K3_WAVES * (n <= 256 ? 2 : 1);             // rays in flight per workgroup
+    return (int)std::min<int64_t>((n_rays + per_block - 1) / per_block, 256 * 8);
 }
 
 }  // namespace nerfx
 
 using namespace nerfx;
 
-#define K3_DISPATCH(EPL_EXPR, KERNEL, ...)                                                         \
-    switch (EPL_EXPR) {                                                                            \
-        case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                                 \
-        case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                                 \
-        case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break;                                 \
-        case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;                                 \
-        case 5: case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break;                         \
-        default: hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); break;                                \
-    }
+// Lanes per ray and samples per lane for n samples: two rays per wavefront up to 256 samples
+// (16-byte slices when n is 128 or 256), one ray per wavefront beyond.
+#define K3_CASE(EPL, LPR, KERNEL, ...) hipLaunchKernelGGL((KERNEL<EPL, LPR>), __VA_ARGS__)
+#define K3_DISPATCH(N, KERNEL, ...)                                                                \
+    do {                                                                                           \
+        if ((N) <= 32) K3_CASE(1, 32, KERNEL, __VA_ARGS__);                                        \
+        else if ((N) <= 64) K3_CASE(2, 32, KERNEL, __VA_ARGS__);                                   \
+        else if ((N) <= 96) K3_CASE(3, 32, KERNEL, __VA_ARGS__);                                   \
+        else if ((N) <= 128) K3_CASE(4, 32, KERNEL, __VA_ARGS__);                                  \
+        else if ((N) <= 192) K3_CASE(6, 32, KERNEL, __VA_ARGS__);                                  \
+        else if ((N) <= 256) K3_CASE(8, 32, KERNEL, __VA_ARGS__);                                  \
+        else if ((N) <= 384) K3_CASE(6, 64, KERNEL, __VA_ARGS__);                                  \
+        else K3_CASE(8, 64, KERNEL, __VA_ARGS__);                                                  \
+    } while (0)
 
 static int composite_check(const float* sigma, const float* t, const float* rd, const float* delta,
                            int64_t n_rays, int n) {
@@ -223,8 +281,7 @@ extern "C" int nerfx_composite_fwd(const float* sigma, const float* rgb, const f
     if (n_rays == 0) return 0;
     NERFX_REQUIRE(!(rgb_map && !rgb), "rgb_map requested without rgb");
     NERFX_REQUIRE(!(depth_map && !t), "depth_map requested without t");
-    const int epl = (n + 63) / 64;
-    K3_DISPATCH(epl, composite_fwd_kernel, dim3(composite_grid(n_rays)), dim3(64 * K3_WAVES), 0,
+    K3_DISPATCH(n, composite_fwd_kernel, dim3(composite_grid(n_rays, n)), dim3(64 * K3_WAVES), 0,
                 (hipStream_t)stream, sigma, rgb, t, rd, delta, n_rays, n, weights, rgb_map, depth_map);
     return launch_status("composite_fwd_kernel");
 }
@@ -238,8 +295,7 @@ extern "C" int nerfx_composite_bwd(const float* sigma, const float* rgb, const f
     NERFX_REQUIRE(g_sigma != nullptr, "g_sigma is NULL");
     NERFX_REQUIRE(!(g_rgb_map && !rgb), "g_rgb_map given without rgb");
     NERFX_REQUIRE(!(g_depth && !t), "g_depth given without t");
-    const int epl = (n + 63) / 64;
-    K3_DISPATCH(epl, composite_bwd_kernel, dim3(composite_grid(n_rays)), dim3(64 * K3_WAVES), 0,
+    K3_DISPATCH(n, composite_bwd_kernel, dim3(composite_grid(n_rays, n)), dim3(64 * K3_WAVES), 0,
                 (hipStream_t)stream, sigma, rgb, t, rd, delta, n_rays, n, g_rgb_map, g_depth, g_weights,
                 g_sigma, g_rgb);
     return launch_status("composite_bwd_kernel");

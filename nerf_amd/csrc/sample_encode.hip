@@ -82,6 +82,26 @@ __global__ __launch_bounds__(K1_THREADS) void sample_encode_kernel(
     }
 }
 
+// The form the render path launches: z values (and optionally segment lengths) only, one
+// thread per sample, so a wavefront writes 256 contiguous bytes per output.  The neighbour's z
+// value is recomputed rather than exchanged.
+__global__ __launch_bounds__(256) void sample_t_kernel(const float* __restrict__ rd, int64_t n_rays, float tn, float tf,
+                                                       int n, const float* __restrict__ u, float* __restrict__ t_out,
+                                                       float* __restrict__ delta_out) {
+    const int64_t total = n_rays * n;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t ray = q / n;
+        const int i = (int)(q - ray * n);
+        const float t = u ? stratified_at(tn, tf, n, i, u[q]) : linspace_at(tn, tf, n, i);
+        if (t_out) t_out[q] = t;
+        if (delta_out) {                                               // ray.py:62-65
+            float d = 1e10f;
+            if (i + 1 < n) d = __fsub_rn(u ? stratified_at(tn, tf, n, i + 1, u[q + 1]) : linspace_at(tn, tf, n, i + 1), t);
+            delta_out[q] = __fmul_rn(d, norm3(rd[3 * ray], rd[3 * ray + 1], rd[3 * ray + 2]));
+        }
+    }
+}
+
 __global__ __launch_bounds__(K1_THREADS) void encode_points_kernel(
     const float* __restrict__ v, int64_t n_points, int kind, int n, const float* __restrict__ table,
     float* __restrict__ phi) {
@@ -128,6 +148,12 @@ extern "C" int nerfx_sample_encode_fwd(const float* ro, const float* rd, int64_t
     NERFX_REQUIRE(ro && rd, "ro / rd is NULL");
     if (phi_x) { int e = check_encoder(kx, nx, tx, "phi_x"); if (e) return e; }
     if (phi_d) { int e = check_encoder(kd, nd, td, "phi_d"); if (e) return e; }
+    if (!rx && !phi_x && !phi_d) {
+        const int grid = (int)std::min<int64_t>((n_rays * n_samples + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(sample_t_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rd, n_rays, tn, tf, n_samples, u,
+                           t, delta);
+        return launch_status("sample_t_kernel");
+    }
     const int grid = (int)std::min<int64_t>(n_rays, 256 * 16);
     hipLaunchKernelGGL(sample_encode_kernel, dim3(grid), dim3(K1_THREADS), 0, (hipStream_t)stream, ro, rd,
                        n_rays, tn, tf, n_samples, u, kx, nx, tx, kd, nd, td, t, delta, rx, phi_x, phi_d);
