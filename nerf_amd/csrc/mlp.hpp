@@ -125,11 +125,12 @@ struct ModelPlan {
     int n_bwd;
     LayerPlan bwd[MAX_LAYERS];
     int64_t bwd_units;
-    // Training tape rows (see Tape in mlp_fwd_impl.hpp).  The pre-activation tape and the
-    // gradient tape share one row map: encoder slots of x and d, then 32 rows per output tile
-    // of every layer but rgb.2, then the gradients at rgb.2's 3 outputs and at the density
-    // head's pre-activation (gradient tape only).
-    int tape_ex_row, tape_ed_row, tape_z_row[MAX_LAYERS], tape_go_row, tape_gs_row, tape_rows;
+    // Training tape tiles (see Tape in mlp_fwd_impl.hpp).  The pre-activation tape and the
+    // gradient tape share one tile map: encoder slots of x and of d (32 per tile), then the output
+    // tiles of every layer but rgb.2, then one "heads" tile (gradient tape only) whose positions
+    // 0..2 are the gradients at rgb.2's outputs and position 3 the one at the density head's
+    // pre-activation.
+    int tape_ex_tile, tape_ed_tile, tape_z_tile[MAX_LAYERS], tape_heads_tile, tape_tiles;
 };
 
 __host__ __device__ inline int units_of(const LayerPlan& L) { return (L.n_tiles / L.group) * (L.enc_seg + L.chain_seg); }
@@ -137,7 +138,7 @@ __host__ __device__ inline int units_of(const LayerPlan& L) { return (L.n_tiles 
 // Fills `p` from a model description; returns 0 or an error code.
 int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p);
 
-// Samples per tape row for n_points samples: whole workgroup blocks of either kernel family
+// Samples per tape tile for n_points samples: whole workgroup blocks of either kernel family
 // and whole sample chunks of the weight-gradient kernel.
 inline uint64_t tape_m_pad(int64_t n_points) { return ((uint64_t)n_points + 255) / 256 * 256; }
 

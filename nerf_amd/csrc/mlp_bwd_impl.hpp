@@ -6,7 +6,7 @@
 //     G_{l-1} = W_l[:, chained columns]^T . Gz_l ,      Gz_{l-1} = G_{l-1} * act'(z_{l-1}),
 // and the weights come from the model's BACKWARD unit stream (transposed blocks, packed by
 // model.hip).  z is read from the tape the training forward wrote; every Gz is written to the
-// gradient tape (same row map), from which the weight-gradient kernel forms dW = Gz . X^T.
+// gradient tape (same tile map), from which the weight-gradient kernel forms dW = Gz^T . X.
 // Gradients with respect to the encodings are never formed: positions and directions are
 // inputs of the reference's training step, not parameters.
 #pragma once
@@ -19,14 +19,14 @@ struct BwdArgs {
     const float* consts;         // const block (global): the density head's weights are used
     const void* ztape;           // pre-activations (training forward)
     void* gtape;                 // receives the pre-activation gradients
-    uint64_t m_pad;              // elements per tape row
+    uint64_t m_pad;              // samples per tape tile
     const float* g_sigma;        // (M)
     const float* g_rgb;          // (M,3)
     const float* sigma;          // (M)   forward outputs: the output activations' derivatives
     const float* rgb;            // (M,3) are formed from them
     uint32_t n_points, n_blocks, n_pieces;
     int hd, sigw_off, const_floats;
-    int z_row[MAX_LAYERS], go_row, gs_row;
+    int z_tile[MAX_LAYERS], heads_tile;
 };
 
 template <int PREC, int ACT>
@@ -43,11 +43,11 @@ __device__ __forceinline__ float activation_slope(float z) {
 // One step of the chain.  hin: Gz of the later layer (CT tiles); the product lands in NT
 // tiles, gets the density head's contribution (SIGMA: + w_sigma[f] * gs), is multiplied by
 // act'(z) of the rows it belongs to (ACT < 0: a plain Linear, no factor), is stored to the
-// gradient tape at `row` and becomes hout.
+// gradient tape at tiles `tile0`.. and becomes hout.
 template <int PREC, class RG, int ACT, int NT, int CT, bool SIGMA, int HN_IN, int HN_OUT>
 __device__ __forceinline__ void linear_bwd(WeightRing<RG>& ring, int h, const typename Prec<PREC>::Frag (&hin)[HN_IN],
                                            typename Prec<PREC>::Frag (&hout)[HN_OUT], const Tape<PREC>& ztape,
-                                           const Tape<PREC>& gtape, int row, lds_floats_t sigw, float gs) {
+                                           const Tape<PREC>& gtape, int tile0, lds_floats_t sigw, float gs) {
     using P = Prec<PREC>;
     constexpr int NG = group_tiles(PREC, NT);
     constexpr int SYNC_PIECES = RG::SYNC;
@@ -90,11 +90,11 @@ __device__ __forceinline__ void linear_bwd(WeightRing<RG>& ring, int h, const ty
                 }
             }
             if (ACT >= 0) {
-                const f32x16 z = ztape.load_tile(row + 32 * tile, h);
+                const f32x16 z = ztape.load_tile(tile0 + tile, h);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] *= activation_slope<PREC, ACT>(z[r]);
             }
-            gtape.store_tile(row + 32 * tile, h, acc[t]);
+            gtape.store_tile(tile0 + tile, h, acc[t]);
 #pragma unroll
             for (int s = 0; s < P::UPT; ++s) hout[tile * P::UPT + s] = P::from_acc(acc[t], s);
         }
@@ -136,10 +136,10 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         }
         const Tape<PREC> zt{(typename Tape<PREC>::T*)a.ztape, a.m_pad, m};
         const Tape<PREC> gt{(typename Tape<PREC>::T*)a.gtape, a.m_pad, m};
-        if (h == 0) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) *gt.at(a.go_row + c) = (typename Tape<PREC>::T)go[c];
-            *gt.at(a.gs_row) = (typename Tape<PREC>::T)gs;
+        if (h == 0) {                                               // heads tile: positions 0..2 and 3
+            using TT = typename Tape<PREC>::T;
+            TT* p = gt.at(a.heads_tile, 0);
+            p[0] = (TT)go[0]; p[1] = (TT)go[1]; p[2] = (TT)go[2]; p[3] = (TT)gs;
         }
         // rgb.2's gradient as a 32-row tile: rows 0..2 are registers 0..2 of lane half 0
         f32x16 top;
@@ -149,18 +149,18 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         Frag A[HN], B[HN];
 #pragma unroll
         for (int s = 0; s < P::UPT; ++s) A[s] = P::from_acc(top, s);
-        linear_bwd<PREC, RG, ACT, RT, 1, false>(ring, h, A, B, zt, gt, a.z_row[feat + 1], sigw, gs);   // -> rgb.0
-        linear_bwd<PREC, RG, -1, WT, RT, false>(ring, h, B, A, zt, gt, a.z_row[feat], sigw, gs);       // -> features
-        linear_bwd<PREC, RG, ACT, WT, WT, true>(ring, h, A, B, zt, gt, a.z_row[feat - 1], sigw, gs);   // -> last trunk layer
+        linear_bwd<PREC, RG, ACT, RT, 1, false>(ring, h, A, B, zt, gt, a.z_tile[feat + 1], sigw, gs);   // -> rgb.0
+        linear_bwd<PREC, RG, -1, WT, RT, false>(ring, h, B, A, zt, gt, a.z_tile[feat], sigw, gs);       // -> features
+        linear_bwd<PREC, RG, ACT, WT, WT, true>(ring, h, A, B, zt, gt, a.z_tile[feat - 1], sigw, gs);   // -> last trunk layer
         // trunk layers feat-1 .. 1, each producing the gradient of the layer below it
         int li = feat - 1;
         if (li >= 1) {
-            linear_bwd<PREC, RG, ACT, WT, WT, false>(ring, h, B, A, zt, gt, a.z_row[li - 1], sigw, gs);
+            linear_bwd<PREC, RG, ACT, WT, WT, false>(ring, h, B, A, zt, gt, a.z_tile[li - 1], sigw, gs);
             --li;
         }
         for (; li >= 2; li -= 2) {
-            linear_bwd<PREC, RG, ACT, WT, WT, false>(ring, h, A, B, zt, gt, a.z_row[li - 1], sigw, gs);
-            linear_bwd<PREC, RG, ACT, WT, WT, false>(ring, h, B, A, zt, gt, a.z_row[li - 2], sigw, gs);
+            linear_bwd<PREC, RG, ACT, WT, WT, false>(ring, h, A, B, zt, gt, a.z_tile[li - 1], sigw, gs);
+            linear_bwd<PREC, RG, ACT, WT, WT, false>(ring, h, B, A, zt, gt, a.z_tile[li - 2], sigw, gs);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -51,8 +51,8 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
         a.tape = tape;
         a.tape_m_pad = tape_m_pad(n_points);
         a.n_blocks = (uint32_t)(a.tape_m_pad / (32 * waves));       // pad columns are written too
-        a.tape_ex_row = p.tape_ex_row; a.tape_ed_row = p.tape_ed_row;
-        for (int li = 0; li < p.n_layers; ++li) a.tape_z_row[li] = p.tape_z_row[li];
+        a.tape_ex_tile = p.tape_ex_tile; a.tape_ed_tile = p.tape_ed_tile;
+        for (int li = 0; li < p.n_layers; ++li) a.tape_z_tile[li] = p.tape_z_tile[li];
         return (precision == NERFX_PREC_BF16 ? launch_mlp_bf16_train : launch_mlp_fp32_train)(p.desc.activ, p.wt, a, (hipStream_t)stream);
     }
     // encoders that fit the kernels' register cache take the fast instantiations
@@ -89,7 +89,7 @@ TrainWorkspace carve_train(const nerfx_model_t* model, int precision, int64_t n_
     const ModelPlan& p = model->plan[precision];
     TrainWorkspace w{};
     w.m_pad = tape_m_pad(n_points);
-    const int64_t tape_bytes = (int64_t)p.tape_rows * (int64_t)w.m_pad * (precision == NERFX_PREC_BF16 ? 2 : 4);
+    const int64_t tape_bytes = (int64_t)p.tape_tiles * (int64_t)w.m_pad * 32 * (precision == NERFX_PREC_BF16 ? 2 : 4);
     char* c = (char*)base;
     w.ztape = c; c += tape_bytes;
     w.gtape = c; c += tape_bytes;
@@ -154,8 +154,8 @@ extern "C" int nerfx_mlp_bwd(const nerfx_model_t* model, int precision, int64_t 
     a.n_blocks = (uint32_t)(w.m_pad / (32 * waves));
     a.n_pieces = (uint32_t)(p.bwd_units / PIECE_UNITS);
     a.hd = p.hd; a.sigw_off = p.sigw_off; a.const_floats = p.const_floats;
-    for (int li = 0; li < p.n_layers; ++li) a.z_row[li] = p.tape_z_row[li];
-    a.go_row = p.tape_go_row; a.gs_row = p.tape_gs_row;
+    for (int li = 0; li < p.n_layers; ++li) a.z_tile[li] = p.tape_z_tile[li];
+    a.heads_tile = p.tape_heads_tile;
     if (int rc = (precision == NERFX_PREC_BF16 ? launch_mlp_bwd_bf16 : launch_mlp_bwd_fp32)(p.desc.activ, p.wt, a, (hipStream_t)stream))
         return rc;
     return launch_wgrad(model, precision, w.m_pad, w.ztape, w.gtape, w.partial, grads, n_grads, (hipStream_t)stream);

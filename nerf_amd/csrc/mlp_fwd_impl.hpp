@@ -53,9 +53,9 @@ struct MlpArgs {
     int ex_kind, ex_n, ex_units, ed_kind, ed_n, ed_units;
     int sigw_off, sigb_off, tabx_off, tabd_off, const_floats;
     unsigned long long* stamps;  // diagnostic builds: 6 cycle buckets, else NULL
-    void* tape;                  // training forward: feature-major tape (see Tape), else NULL
-    uint64_t tape_m_pad;         // elements per tape row
-    int tape_ex_row, tape_ed_row, tape_z_row[MAX_LAYERS];   // first row of each encoder / layer
+    void* tape;                  // training forward: the tape to record (see Tape), else NULL
+    uint64_t tape_m_pad;         // samples per tape tile
+    int tape_ex_tile, tape_ed_tile, tape_z_tile[MAX_LAYERS];   // first tile of each encoder / layer
 };
 
 // ---- optional in-kernel cycle accounting (diagnostic builds only: -DNERFX_STAMPS) -------
@@ -82,26 +82,64 @@ struct Stamps {
 enum { ST_PROLOGUE = 0, ST_ACQUIRE = 1, ST_RUN = 2, ST_EPILOGUE = 3, ST_HEADS = 4, ST_ENCODE = 5 };
 
 // ---- training tape -------------------------------------------------------------------------
-// Feature-major scratch in HBM shared by the training forward, the backward chain and the
-// weight-gradient kernels: row f holds feature f of every sample (`m_pad` elements, bf16 or
-// fp32 with the kernel's precision).  A wavefront holds a 32x32 tile with its sample on the
-// lane, so register r of a tile is one element of row (r&3) + 8 (r>>2) + 4 h.
+// Scratch in HBM shared by the training forward, the backward chain and the weight-gradient
+// kernel: an array of TILES [tile][sample][32 positions] (bf16 or fp32 with the kernel's
+// precision; `m_pad` samples per tile).  A tile is 32 features of every sample, stored the way
+// the producing wavefront holds it: lane half h of a sample's lane owns positions 16 h .. 16 h + 15
+// = its 16 accumulator registers in order, so register r of half h (feature
+// (r & 3) + 8 (r >> 2) + 4 h of the tile) sits at position 16 h + r, a lane moves 32 (64) contiguous
+// bytes and a wavefront 2 (4) KiB.  Encoder tiles hold 32 consecutive encoder slots in slot order.
 template <int PREC>
 struct Tape {
-    using T = typename std::conditional<PREC == NERFX_PREC_BF16, __bf16, float>::type;
+    static constexpr bool BF16 = PREC == NERFX_PREC_BF16;
+    using T = typename std::conditional<BF16, __bf16, float>::type;
+    using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
     T* base;
     uint64_t m_pad;
-    uint32_t m;                  // this lane's sample column
-    __device__ __forceinline__ T* at(int row) const { return base + (uint64_t)row * m_pad + m; }
-    __device__ __forceinline__ void store_tile(int row0, int h, const f32x16& v) const {
+    uint32_t m;                  // this lane's sample
+    __device__ __forceinline__ T* at(int tile, int pos) const { return base + ((uint64_t)tile * m_pad + m) * 32 + pos; }
+    // (callers make sure `v` does not come straight out of an MFMA: the bf16 form converts in asm)
+    __device__ __forceinline__ void store_tile(int tile, int h, const f32x16& v) const {
+        T* p = at(tile, 16 * h);
+        if constexpr (BF16) {
+            using P = uint32_t (*)(float, float);
+            auto pk = [](float lo, float hi) { uint32_t r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; };
+            (void)sizeof(P);
+            reinterpret_cast<u32x4*>(p)[0] = u32x4{pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7])};
+            reinterpret_cast<u32x4*>(p)[1] = u32x4{pk(v[8], v[9]), pk(v[10], v[11]), pk(v[12], v[13]), pk(v[14], v[15])};
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) *at(row0 + (r & 3) + 8 * (r >> 2) + 4 * h) = (T)v[r];
+            for (int q = 0; q < 4; ++q) reinterpret_cast<f32x4*>(p)[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        }
     }
-    __device__ __forceinline__ f32x16 load_tile(int row0, int h) const {
+    __device__ __forceinline__ f32x16 load_tile(int tile, int h) const {
+        const T* p = at(tile, 16 * h);
         f32x16 v;
+        if constexpr (BF16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = (float)*at(row0 + (r & 3) + 8 * (r >> 2) + 4 * h);
+            for (int q = 0; q < 2; ++q) {
+                const u32x4 w = reinterpret_cast<const u32x4*>(p)[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[8 * q + 2 * e] = __builtin_bit_cast(float, w[e] << 16);
+                    v[8 * q + 2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xFFFF0000u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w = reinterpret_cast<const f32x4*>(p)[q];
+                v[4 * q] = w[0]; v[4 * q + 1] = w[1]; v[4 * q + 2] = w[2]; v[4 * q + 3] = w[3];
+            }
+        }
         return v;
+    }
+    // B operand of encoder k-unit u (16 slots in bf16, 8 in fp32; lane half h supplies half of them)
+    template <class Frag>
+    __device__ __forceinline__ void store_enc(int tile0, int u, int h, const Frag& f) const {
+        constexpr int SPU = BF16 ? 16 : 8;
+        const int slot = SPU * u + (SPU / 2) * h;
+        *reinterpret_cast<Frag*>(at(tile0 + slot / 32, slot % 32)) = f;
     }
 };
 
@@ -352,8 +390,8 @@ constexpr bool uses_stash() { return PREC == NERFX_PREC_BF16 && !BIGENC && WT >=
 //   with_enc: this layer's stream carries an encoder segment (wave-uniform)
 //   SIGMA: also accumulate the density head's dot product on the fp32 activations
 //   raw  : if non-null (NT == 1 only) receives the fp32 accumulator tile instead of hout
-//   ztape: training forward (TRAIN): the pre-activation output goes to tape rows zrow..;
-//          with an encoder segment, its B operands go to rows erow.. in slot order
+//   ztape: training forward (TRAIN): the pre-activation output goes to tape tiles ztile..;
+//          with an encoder segment, its B operands go to tiles etile.. in slot order
 template <int PREC, class RG, int ACT, bool BIGENC, int NT, int CT, bool SIGMA, bool STASH = false, bool TRAIN = false,
           int HN_IN = 0, int HN_OUT = 0>
 __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias, int h,
@@ -361,7 +399,7 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
                                         typename Prec<PREC>::Frag (&hout)[HN_OUT],
                                         bool with_enc, const Encoding<PREC>& enc, lds_floats_t sigw,
                                         Stamps& st, f32x16* raw = nullptr, uint32_t stash = 0,
-                                        const Tape<PREC>* ztape = nullptr, int zrow = 0, int erow = -1) {
+                                        const Tape<PREC>* ztape = nullptr, int ztile = 0, int etile = -1) {
     using P = Prec<PREC>;
     constexpr int NG = group_tiles(PREC, NT);
     constexpr int SYNC_PIECES = RG::SYNC;
@@ -406,12 +444,9 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
 #pragma unroll
                     for (int u = 0; u < ENC_BLOCK; ++u) eb[u] = enc.eval(u0 + u);
                     if constexpr (TRAIN) {
-                        if (grp == 0 && erow >= 0) {               // slot s of the encoding -> tape row erow + s
+                        if (grp == 0 && etile >= 0) {
 #pragma unroll
-                            for (int u = 0; u < ENC_BLOCK; ++u)
-#pragma unroll
-                                for (int e = 0; e < P::SPUH; ++e)
-                                    *ztape->at(erow + enc_unit_slot(PREC, u0 + u, h, e)) = eb[u][e];
+                            for (int u = 0; u < ENC_BLOCK; ++u) ztape->store_enc(etile, u0 + u, h, eb[u]);
                         }
                     }
                     ring.template acquire<ENC_PIECES>();
@@ -446,7 +481,7 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
         }
         if constexpr (TRAIN) {
 #pragma unroll
-            for (int t = 0; t < NG; ++t) ztape->store_tile(zrow + 32 * (grp * NG + t), h, acc[t]);
+            for (int t = 0; t < NG; ++t) ztape->store_tile(ztile + grp * NG + t, h, acc[t]);
         }
         // epilogue: activation, density dot, conversion to the next layer's operands
         constexpr bool packed_relu = ACT == NERFX_ACT_RELU && P::PACKED_RELU && !SIGMA;
@@ -559,8 +594,8 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         // ---- fc_1 then fc_2; fc_2's first layer optionally sees [phi_x | h] (model.py:71-73).
         // Layer 0 writes A; the remaining 2 hd - 1 trunk layers alternate A -> B, B -> A, so the
         // last one always lands in B.
-        if (last == 0) dot = linear<PREC, RG, ACT, BIGENC, WT, 0, true, STASH, TRAIN>(ring, cst, h, A, B, true, enc, sigw, st, nullptr, stash, zt, a.tape_z_row[0], a.tape_ex_row);
-        else linear<PREC, RG, ACT, BIGENC, WT, 0, false, STASH, TRAIN>(ring, cst, h, B, A, true, enc, sigw, st, nullptr, stash, zt, a.tape_z_row[0], a.tape_ex_row);
+        if (last == 0) dot = linear<PREC, RG, ACT, BIGENC, WT, 0, true, STASH, TRAIN>(ring, cst, h, A, B, true, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[0], a.tape_ex_tile);
+        else linear<PREC, RG, ACT, BIGENC, WT, 0, false, STASH, TRAIN>(ring, cst, h, B, A, true, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[0], a.tape_ex_tile);
         const int skip = resid ? hd : -1;                          // the layer that sees phi_x again
         auto refresh = [&](int li) {                               // register-resident encodings only
             if (!STASH && li == skip) {
@@ -573,13 +608,13 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
 #pragma unroll
         for (; li + 1 <= last; li += 2) {
             refresh(li);
-            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN>(ring, cst + li * BIAS_STRIDE, h, A, B, li == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_row[li]);
+            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN>(ring, cst + li * BIAS_STRIDE, h, A, B, li == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[li]);
             refresh(li + 1);
-            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN>(ring, cst + (li + 1) * BIAS_STRIDE, h, B, A, li + 1 == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_row[li + 1]);
+            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN>(ring, cst + (li + 1) * BIAS_STRIDE, h, B, A, li + 1 == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[li + 1]);
         }
         if (last > 0) {
             refresh(last);
-            dot = linear<PREC, RG, ACT, BIGENC, WT, WT, true, STASH, TRAIN>(ring, cst + last * BIAS_STRIDE, h, A, B, last == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_row[last]);
+            dot = linear<PREC, RG, ACT, BIGENC, WT, WT, true, STASH, TRAIN>(ring, cst + last * BIAS_STRIDE, h, A, B, last == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[last]);
         }
         // ---- density head (model.py:75, activations.py:33-35) ------------------------------
         st.mark(ST_EPILOGUE);
@@ -594,11 +629,11 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         if (colour) {
             li = last + 1;
             // ---- features: Linear without activation (model.py:51, :76): B -> A ------------
-            linear<PREC, RG, -1, BIGENC, WT, WT, false, false, TRAIN>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, st, nullptr, 0, zt, a.tape_z_row[li]);
+            linear<PREC, RG, -1, BIGENC, WT, WT, false, false, TRAIN>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li]);
             ++li;
             // ---- rgb.0 on [phi_d | features] (model.py:53, :76): A -> B ---------------------
             { st.mark(ST_EPILOGUE); enc.template prepare<BIGENC>(a.ed_kind, a.ed_units, cst + a.tabd_off, h, dx, dy, dz); st.mark(ST_ENCODE); }
-            linear<PREC, RG, ACT, BIGENC, RT, WT, false, false, TRAIN>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw, st, nullptr, 0, zt, a.tape_z_row[li], a.tape_ed_row);
+            linear<PREC, RG, ACT, BIGENC, RT, WT, false, false, TRAIN>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li], a.tape_ed_tile);
             ++li;
             // ---- rgb.2 + widened sigmoid (model.py:54, activations.py:18-20) ----------------
             f32x16 out;

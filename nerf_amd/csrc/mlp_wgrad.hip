@@ -1,14 +1,17 @@
 // K2b, part 2: weight and bias gradients of the MLP from the two training tapes.
 //
-//     dW_l[o][i] = sum over samples m of  Gz_l[o][m] * X_l[i][m]
+//     dW_l[o][i] = sum over samples m of  Gz_l[m][o] * X_l[m][i]
 //
-// Both tapes are feature-major (one row per feature, samples contiguous), so Gz rows are the
-// MFMA A operand and X rows the B operand with the SAMPLE index as the contraction: a lane
-// feeds 16 bytes of its row per step, straight from memory.  X is rebuilt on load from the
-// pre-activation tape (activation of z, or the stored encoder slot, or the constant 1 whose
-// "weight" gradient is the bias gradient).  The sample range is split over wavefronts; every
-// (task, split) wavefront writes a 64 x 64 fp32 partial, and a second kernel adds the partials
-// in a fixed order and scatters them into torch-layout gradients -- deterministic, no atomics.
+// Both tapes are arrays of TILES [tile][sample][32 positions] (see Tape): a tile holds 32
+// features of every sample, sample-major, exactly as the producing wavefronts had them in
+// registers.  The contraction runs over samples, i.e. over the ROWS of both operands, so a
+// workgroup stages a chunk of samples of up to 4 gradient tiles and 4 input tiles in LDS with
+// plain 16-byte copies (the activation of z, which makes X, is applied on the way) and its four
+// wavefronts read the MFMA operands transposed: ds_read_b64_tr_b16 for bf16, one dword per lane
+// for the fp32 32x32x2 form.  X is the stored encoder slot, the activation of the previous
+// layer's z, or the constant 1 whose "weight" gradient is the bias gradient.  The sample range
+// is split over workgroups; every (task, split) writes fp32 partials and a second kernel adds
+// them in a fixed order and scatters into torch-layout gradients: deterministic, no atomics.
 #include "mlp_fwd_impl.hpp"
 
 #include <vector>
@@ -16,62 +19,64 @@
 namespace nerfx {
 
 enum { WB_RAW = 0, WB_ACT = 1, WB_ONES = 2 };       // how an input tile becomes X
-enum { WM_ENC = 0, WM_CHAIN = 1, WM_BIAS = 2 };     // where an input tile's columns go
+enum { WM_ENC = 0, WM_CHAIN = 1, WM_BIAS = 2 };     // where an input tile's positions go
+enum { WO_LAYER = 0, WO_RGB = 1, WO_SIGMA = 2 };    // which weight rows a gradient tile's positions are
+constexpr int WG_SIDE = 4;                          // tiles per side of a workgroup's block
 
-// A 64 x 64 block of one layer's gradient: two 32-row tiles of Gz against two 32-row tiles of X.
+// A block of one layer's gradient: up to 4 gradient tiles against up to 4 input tiles.
 struct WTask {
-    int a_row[2], a_valid[2];                      // gradient-tape rows; valid = 0: tile absent
-    int b_row[2], b_valid[2], b_kind[2];           // pre-activation-tape rows
-    int out0[2];                                   // first weight row of each output tile
-    int map_kind[2], map0[2];                      // WM_*, first slot / feature of each input tile
+    int n_a, n_b;
+    int a_tile[WG_SIDE], a_kind[WG_SIDE], a_row0[WG_SIDE];                     // gradient tape
+    int b_tile[WG_SIDE], b_kind[WG_SIDE], b_map[WG_SIDE], b_col0[WG_SIDE];     // pre-activation tape
     int w_index, b_index;                          // positions of weight and bias in the gradient list
-    int enc_kind, enc_n, enc_cols, ld, chain_dim;
+    int out_dim, enc_kind, enc_n, enc_cols, ld, chain_dim;
 };
 
 struct GradList { float* p[2 + 2 * MAX_LAYERS + 8]; };
 
 static void build_tasks(const ModelPlan& p, std::vector<WTask>& out) {
-    struct Tile { int row, valid, kind, map_kind, map0; };
+    struct A { int tile, kind, row0; };
+    struct B { int tile, kind, map, col0; };
     const int spu = slots_per_unit(p.prec);
     const int hd = p.hd, n_jobs = p.n_layers + 1;                   // every Linear + the density head
     for (int job = 0; job < n_jobs; ++job) {
         const bool sigma = job == p.n_layers;
         const LayerPlan& L = p.layer[sigma ? 2 * hd : job];          // density head: same input as `features`
-        std::vector<Tile> outs, ins;
-        int w_index;
+        std::vector<A> outs;
+        std::vector<B> ins;
+        int w_index, out_dim;
         if (sigma) {
-            outs.push_back({p.tape_gs_row, 1, 0, 0, 0});
-            w_index = 2 + 4 * hd;
+            outs.push_back({p.tape_heads_tile, WO_SIGMA, 0});
+            w_index = 2 + 4 * hd; out_dim = 1;
         } else {
             w_index = job < 2 * hd ? 2 + 2 * job : 2 + 4 * hd + 2 + 2 * (job - 2 * hd);
-            if (job == p.n_layers - 1) outs.push_back({p.tape_go_row, 3, 0, 0, 0});
+            out_dim = L.out_dim;
+            if (job == p.n_layers - 1) outs.push_back({p.tape_heads_tile, WO_RGB, 0});
             else
                 for (int t = 0; t < L.n_tiles; ++t)
-                    if (L.out_dim > 32 * t) outs.push_back({p.tape_z_row[job] + 32 * t, std::min(32, L.out_dim - 32 * t), 0, 0, 32 * t});
+                    if (L.out_dim > 32 * t) outs.push_back({p.tape_z_tile[job] + t, WO_LAYER, 32 * t});
         }
         if (!sigma && L.enc_units) {
-            const int base = job == 2 * hd + 1 ? p.tape_ed_row : p.tape_ex_row;   // rgb.0 sees phi_d
-            for (int s = 0; s < L.enc_units * spu; s += 32) ins.push_back({base + s, 32, WB_RAW, WM_ENC, s});
+            const int base = job == 2 * hd + 1 ? p.tape_ed_tile : p.tape_ex_tile;   // rgb.0 sees phi_d
+            for (int t = 0; t < L.enc_units * spu / 32; ++t) ins.push_back({base + t, WB_RAW, WM_ENC, 32 * t});
         }
         if (L.chain_tiles) {
             const int src = sigma ? 2 * hd - 1 : job - 1;            // the layer whose output feeds this one
             const int kind = src == 2 * hd ? WB_RAW : WB_ACT;        // `features` has no activation
             for (int t = 0; t < L.chain_tiles; ++t)
-                if (L.chain_dim > 32 * t)
-                    ins.push_back({p.tape_z_row[src] + 32 * t, std::min(32, L.chain_dim - 32 * t), kind, WM_CHAIN, 32 * t});
+                if (L.chain_dim > 32 * t) ins.push_back({p.tape_z_tile[src] + t, kind, WM_CHAIN, 32 * t});
         }
-        ins.push_back({0, 1, WB_ONES, WM_BIAS, 0});
-        for (size_t o = 0; o < outs.size(); o += 2)
-            for (size_t i = 0; i < ins.size(); i += 2) {
+        ins.push_back({0, WB_ONES, WM_BIAS, 0});
+        for (size_t o = 0; o < outs.size(); o += WG_SIDE)
+            for (size_t i = 0; i < ins.size(); i += WG_SIDE) {
                 WTask k{};
-                for (int s = 0; s < 2; ++s) {
-                    if (o + s < outs.size()) { k.a_row[s] = outs[o + s].row; k.a_valid[s] = outs[o + s].valid; k.out0[s] = outs[o + s].map0; }
-                    if (i + s < ins.size()) {
-                        const Tile& T = ins[i + s];
-                        k.b_row[s] = T.row; k.b_valid[s] = T.valid; k.b_kind[s] = T.kind; k.map_kind[s] = T.map_kind; k.map0[s] = T.map0;
-                    }
+                k.n_a = (int)std::min<size_t>(WG_SIDE, outs.size() - o);
+                k.n_b = (int)std::min<size_t>(WG_SIDE, ins.size() - i);
+                for (int s = 0; s < k.n_a; ++s) { k.a_tile[s] = outs[o + s].tile; k.a_kind[s] = outs[o + s].kind; k.a_row0[s] = outs[o + s].row0; }
+                for (int s = 0; s < k.n_b; ++s) {
+                    k.b_tile[s] = ins[i + s].tile; k.b_kind[s] = ins[i + s].kind; k.b_map[s] = ins[i + s].map; k.b_col0[s] = ins[i + s].col0;
                 }
-                k.w_index = w_index; k.b_index = w_index + 1;
+                k.w_index = w_index; k.b_index = w_index + 1; k.out_dim = out_dim;
                 k.enc_kind = L.enc_kind; k.enc_n = L.enc_n;
                 k.enc_cols = sigma ? 0 : L.enc_cols; k.ld = sigma ? L.chain_dim : L.in_dim; k.chain_dim = L.chain_dim;
                 out.push_back(k);
@@ -79,16 +84,17 @@ static void build_tasks(const ModelPlan& p, std::vector<WTask>& out) {
     }
 }
 
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+
 template <int PREC> struct WOperand;
 template <> struct WOperand<NERFX_PREC_BF16> {
     using T = __bf16;
-    using V = bf16x8;
-    static constexpr int EPL = 8;
+    using V = bf16x8;                              // 16 bytes as copied
+    static constexpr int EPV = 8;
+    static constexpr int CHUNK = 64;               // samples staged per step
+    static constexpr int KSTEP = 16;               // samples per MFMA
     static __device__ __forceinline__ V zero() { return __builtin_bit_cast(V, s16x8(0)); }
-    static __device__ __forceinline__ V ones() { return __builtin_bit_cast(V, s16x8(0x3F80)); }
-    static __device__ __forceinline__ void mma(f32x16& acc, const V& a, const V& b) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-    }
+    static __device__ __forceinline__ V one_then_zeros() { s16x8 v(0); v[0] = 0x3F80; return __builtin_bit_cast(V, v); }
     template <int ACT>
     static __device__ __forceinline__ V act(const V& z) {
         if (ACT == NERFX_ACT_RELU) return Prec<NERFX_PREC_BF16>::relu(z);
@@ -97,17 +103,33 @@ template <> struct WOperand<NERFX_PREC_BF16> {
         for (int e = 0; e < 8; ++e) o[e] = (__bf16)activate<NERFX_PREC_BF16, ACT>((float)z[e]);
         return o;
     }
+    // Operand of one 32-position tile for MFMA step kk of the staged chunk: lane (i = lane & 31,
+    // kh = lane >> 5) gets samples 16 kk + 8 kh .. + 7 of position i.  A 16-lane group reads
+    // 4 samples x 16 positions per instruction, transposed by the LDS.
+    using Frag = bf16x8;
+    static __device__ __forceinline__ uint32_t lane_offset(int lane) {
+        const int L = lane & 15, g = lane >> 4;
+        return (uint32_t)((8 * (g >> 1) + (L >> 2)) * 64 + (16 * (g & 1) + 4 * (L & 3)) * 2);
+    }
+    static __device__ __forceinline__ Frag fetch(lds_bytes_t tile, uint32_t lane_off, int kk) {
+        using P4 = __attribute__((address_space(3))) s16x4*;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((P4)(tile + lane_off + kk * 1024));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((P4)(tile + lane_off + kk * 1024 + 256));
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(Frag, v);
+    }
+    static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
 };
 template <> struct WOperand<NERFX_PREC_FP32> {
     using T = float;
     using V = f32x4;
-    static constexpr int EPL = 4;
+    static constexpr int EPV = 4;
+    static constexpr int CHUNK = 32;
+    static constexpr int KSTEP = 2;
     static __device__ __forceinline__ V zero() { return V{0.0f, 0.0f, 0.0f, 0.0f}; }
-    static __device__ __forceinline__ V ones() { return V{1.0f, 1.0f, 1.0f, 1.0f}; }
-    static __device__ __forceinline__ void mma(f32x16& acc, const V& a, const V& b) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
-    }
+    static __device__ __forceinline__ V one_then_zeros() { return V{1.0f, 0.0f, 0.0f, 0.0f}; }
     template <int ACT>
     static __device__ __forceinline__ V act(const V& z) {
         V o;
@@ -115,37 +137,68 @@ template <> struct WOperand<NERFX_PREC_FP32> {
         for (int e = 0; e < 4; ++e) o[e] = activate<NERFX_PREC_FP32, ACT>(z[e]);
         return o;
     }
+    using Frag = float;                            // lane (i, kh): sample 2 kk + kh of position i
+    static __device__ __forceinline__ uint32_t lane_offset(int lane) { return (uint32_t)(((lane >> 5) * 32 + (lane & 31)) * 4); }
+    static __device__ __forceinline__ Frag fetch(lds_bytes_t tile, uint32_t lane_off, int kk) {
+        return NERFX_LDS_VEC(float, tile + lane_off + kk * 256);
+    }
+    static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
 };
 
-constexpr int WG_UNROLL = 4;                        // k-steps loaded together
-
-// One wavefront per (task, sample split).  Lane (i = lane & 31, kh = lane >> 5) supplies elements
-// [k + kh * EPL, k + (kh + 1) * EPL) of row i to both operands.
+// One workgroup (4 wavefronts) per (task, sample split).  Wavefront w accumulates gradient tiles
+// 2 (w >> 1), +1 against input tiles 2 (w & 1), +1.
 template <int PREC, int ACT>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WTask* __restrict__ tasks, int n_tasks, int n_split,
-                                                    uint32_t k_per_split, uint32_t m_pad,
-                                                    const typename WOperand<PREC>::T* __restrict__ ztape,
-                                                    const typename WOperand<PREC>::T* __restrict__ gtape,
-                                                    float* __restrict__ partial) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WTask* __restrict__ tasks, int n_tasks, int chunks_per_split,
+                                                       int n_chunks, uint64_t m_pad,
+                                                       const typename WOperand<PREC>::T* __restrict__ ztape,
+                                                       const typename WOperand<PREC>::T* __restrict__ gtape,
+                                                       float* __restrict__ partial) {
     using O = WOperand<PREC>;
+    using T = typename O::T;
     using V = typename O::V;
-    constexpr int KSTEP = 2 * O::EPL;
-    const int wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (wave_id >= n_tasks * n_split) return;
-    const int ks = wave_id / n_tasks, task = wave_id - ks * n_tasks;
+    constexpr int TILE_BYTES = O::CHUNK * 32 * (int)sizeof(T);     // one tile's chunk in LDS: 4 KiB
+    static_assert(TILE_BYTES == 256 * 16, "one 16-byte copy per thread per tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [2 buffers][8 tiles][TILE_BYTES]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = blockIdx.x / n_tasks, task = blockIdx.x - ks * n_tasks;
     const WTask& tk = tasks[task];
-    const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
-    const typename O::T *pa[2], *pb[2];
-    bool a_on[2], b_on[2];
-    int b_kind[2];
+    const int c0 = ks * chunks_per_split, c1 = min(c0 + chunks_per_split, n_chunks);
+
+    // this thread's 16 bytes of every staged tile: element tid * EPV of the tile's chunk
+    const T* src[2 * WG_SIDE];
+    int kind[2 * WG_SIDE];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        a_on[s] = i < tk.a_valid[s];
-        b_on[s] = i < tk.b_valid[s];
-        b_kind[s] = tk.b_kind[s];
-        pa[s] = gtape + (uint64_t)(tk.a_row[s] + (a_on[s] ? i : 0)) * m_pad + kh * O::EPL;
-        pb[s] = ztape + (uint64_t)(tk.b_row[s] + (b_on[s] ? i : 0)) * m_pad + kh * O::EPL;
+    for (int s = 0; s < WG_SIDE; ++s) {
+        src[s] = gtape + (uint64_t)tk.a_tile[s] * m_pad * 32 + tid * O::EPV;
+        kind[s] = s < tk.n_a ? WB_RAW : -1;
+        src[WG_SIDE + s] = ztape + (uint64_t)tk.b_tile[s] * m_pad * 32 + tid * O::EPV;
+        kind[WG_SIDE + s] = s < tk.n_b ? tk.b_kind[s] : -1;
     }
+    const V ones = (tid * O::EPV) % 32 == 0 ? O::one_then_zeros() : O::zero();   // position 0 of every sample
+    V staged[2 * WG_SIDE];
+    auto stage = [&](int c) {
+        const uint64_t off = (uint64_t)c * O::CHUNK * 32;
+#pragma unroll
+        for (int s = 0; s < 2 * WG_SIDE; ++s)
+            if (kind[s] == WB_RAW || kind[s] == WB_ACT) staged[s] = *reinterpret_cast<const V*>(src[s] + off);
+    };
+    auto commit = [&](int buf) {
+        lds_bytes_t dst = (lds_bytes_t)smem + buf * (2 * WG_SIDE * TILE_BYTES) + tid * 16;
+#pragma unroll
+        for (int s = 0; s < 2 * WG_SIDE; ++s) {
+            if (kind[s] < 0) continue;
+            V v = staged[s];
+            if (kind[s] == WB_ACT) v = O::template act<ACT>(v);
+            if (kind[s] == WB_ONES) v = ones;
+            *reinterpret_cast<__attribute__((address_space(3))) V*>(dst + s * TILE_BYTES) = v;
+        }
+    };
+
+    const int oa = 2 * (wave >> 1), ib = 2 * (wave & 1);
+    const bool a_on[2] = {oa < tk.n_a, oa + 1 < tk.n_a}, b_on[2] = {ib < tk.n_b, ib + 1 < tk.n_b};
+    const uint32_t lane_off = O::lane_offset(lane);
     f32x16 acc[2][2];
 #pragma unroll
     for (int o = 0; o < 2; ++o)
@@ -153,73 +206,83 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WTask* __restrict__ ta
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[o][n][r] = 0.0f;
-    const uint32_t k0 = ks * k_per_split, k1 = min(k0 + k_per_split, m_pad);
-    for (uint32_t k = k0; k < k1; k += WG_UNROLL * KSTEP) {
-        V a[WG_UNROLL][2], b[WG_UNROLL][2];
-#pragma unroll
-        for (int u = 0; u < WG_UNROLL; ++u)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                a[u][s] = *reinterpret_cast<const V*>(pa[s] + k + u * KSTEP);
-                b[u][s] = *reinterpret_cast<const V*>(pb[s] + k + u * KSTEP);
+
+    if (c0 < c1) { stage(c0); commit(0); }
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+        const int buf = (c - c0) & 1;
+        if (c + 1 < c1) stage(c + 1);
+        if (a_on[0] && b_on[0]) {                                   // wave-uniform: this wave has work
+            lds_bytes_t base = (lds_bytes_t)smem + buf * (2 * WG_SIDE * TILE_BYTES);
+            lds_bytes_t ta = base + oa * TILE_BYTES, tb = base + (WG_SIDE + ib) * TILE_BYTES;
+#pragma unroll 4
+            for (int kk = 0; kk < O::CHUNK / O::KSTEP; ++kk) {
+                const typename O::Frag a0 = O::fetch(ta, lane_off, kk), a1 = O::fetch(ta + TILE_BYTES, lane_off, kk);
+                const typename O::Frag b0 = O::fetch(tb, lane_off, kk), b1 = O::fetch(tb + TILE_BYTES, lane_off, kk);
+                O::mma(acc[0][0], a0, b0);
+                O::mma(acc[0][1], a0, b1);
+                O::mma(acc[1][0], a1, b0);
+                O::mma(acc[1][1], a1, b1);
             }
-#pragma unroll
-        for (int u = 0; u < WG_UNROLL; ++u) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                if (!a_on[s]) a[u][s] = O::zero();
-                if (b_kind[s] == WB_ACT) b[u][s] = O::template act<ACT>(b[u][s]);
-                if (b_kind[s] == WB_ONES) b[u][s] = O::ones();
-                if (!b_on[s]) b[u][s] = O::zero();
-            }
-#pragma unroll
-            for (int o = 0; o < 2; ++o)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) O::mma(acc[o][n], a[u][o], b[u][n]);
         }
+        if (c + 1 < c1) commit(buf ^ 1);
+        __syncthreads();
     }
-    float* dst = partial + ((size_t)wave_id * 4) * 1024 + lane * 16;
+    // absent tiles were never staged: their LDS bytes are arbitrary, their products are never stored
+    float* dst = partial + ((size_t)blockIdx.x * (WG_SIDE * WG_SIDE)) * 1024 + lane * 16;
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) *reinterpret_cast<f32x16*>(dst + (o * 2 + n) * 1024) = acc[o][n];
+        for (int n = 0; n < 2; ++n)
+            if (a_on[o] && b_on[n]) *reinterpret_cast<f32x16*>(dst + ((oa + o) * WG_SIDE + ib + n) * 1024) = acc[o][n];
 }
+
+// Position p of a tile written in accumulator-register order -> feature of the 32-feature tile.
+__device__ __forceinline__ int tile_position_feature(int p) { return (p & 3) + 8 * ((p & 15) >> 2) + 4 * (p >> 4); }
 
 // Sums the splits of one task element in split order and writes it where it belongs.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WTask* __restrict__ tasks, int n_tasks, int n_split,
                                                            const float* __restrict__ partial, GradList grads) {
-    const int task = blockIdx.x >> 4, e = ((blockIdx.x & 15) << 8) + threadIdx.x;       // 4096 elements per task
+    constexpr int PER_TASK = WG_SIDE * WG_SIDE * 1024;
+    const int task = blockIdx.x / (PER_TASK / 256), e = (blockIdx.x % (PER_TASK / 256)) * 256 + threadIdx.x;
     const WTask& tk = tasks[task];
     const int tile = e >> 10, lane = (e >> 4) & 63, r = e & 15;
-    const int o = tile >> 1, n = tile & 1;
-    const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = lane & 31;              // out row, in row of the tile
-    if (i >= tk.a_valid[o] || j >= tk.b_valid[n]) return;
-    float sum = 0.0f;
-    for (int ks = 0; ks < n_split; ++ks) sum += partial[((size_t)ks * n_tasks + task) * 4096 + e];
-    const int row = tk.out0[o] + i;
-    if (tk.map_kind[n] == WM_BIAS) {
-        if (grads.p[tk.b_index]) grads.p[tk.b_index][row] = sum;
-        return;
-    }
-    int col;
-    if (tk.map_kind[n] == WM_ENC) {
-        col = enc_slot_col(tk.enc_kind, tk.enc_n, tk.map0[n] + j);
+    const int o = tile / WG_SIDE, n = tile % WG_SIDE;
+    if (o >= tk.n_a || n >= tk.n_b) return;
+    const int po = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), pi = lane & 31;          // positions in the two tiles
+    int row;
+    if (tk.a_kind[o] == WO_LAYER) row = tk.a_row0[o] + tile_position_feature(po);
+    else if (tk.a_kind[o] == WO_RGB) row = po < 3 ? po : -1;
+    else row = po == 3 ? 0 : -1;
+    if (row < 0 || row >= tk.out_dim) return;
+    int col = -1;
+    float* dst = grads.p[tk.w_index];
+    if (tk.b_map[n] == WM_BIAS) {
+        if (pi != 0) return;
+        dst = grads.p[tk.b_index];
+    } else if (tk.b_map[n] == WM_ENC) {
+        col = enc_slot_col(tk.enc_kind, tk.enc_n, tk.b_col0[n] + pi);
+        if (col < 0) return;
     } else {
-        const int f = tk.map0[n] + j;
-        col = f < tk.chain_dim ? tk.enc_cols + f : -1;
+        const int f = tk.b_col0[n] + tile_position_feature(pi);
+        if (f >= tk.chain_dim) return;
+        col = tk.enc_cols + f;
     }
-    if (col >= 0 && grads.p[tk.w_index]) grads.p[tk.w_index][(size_t)row * tk.ld + col] = sum;
+    if (!dst) return;
+    float sum = 0.0f;
+    for (int ks = 0; ks < n_split; ++ks) sum += partial[((size_t)ks * n_tasks + task) * PER_TASK + e];
+    if (col < 0) dst[row] = sum;
+    else dst[(size_t)row * tk.ld + col] = sum;
 }
 
-// Sample splits for a launch: enough wavefronts to fill the device, at least 256 samples each.
-static void split_plan(int n_tasks, uint64_t m_pad, int& n_split, uint32_t& k_per_split) {
-    const uint64_t chunk = 256;
-    const uint64_t max_split = (m_pad + chunk - 1) / chunk;
-    uint64_t want = (4096 + n_tasks - 1) / n_tasks;
-    want = std::max<uint64_t>(1, std::min(want, max_split));
-    k_per_split = (uint32_t)(((m_pad + want - 1) / want + chunk - 1) / chunk * chunk);
-    n_split = (int)((m_pad + k_per_split - 1) / k_per_split);
+// Sample splits for a launch: enough workgroups to fill the device twice over.
+static void split_plan(int n_tasks, int n_chunks, int& n_split, int& chunks_per_split) {
+    int want = (2048 + n_tasks - 1) / n_tasks;
+    want = std::max(1, std::min(want, n_chunks));
+    chunks_per_split = (n_chunks + want - 1) / want;
+    n_split = (n_chunks + chunks_per_split - 1) / chunks_per_split;
 }
+static int chunk_samples(int prec) { return prec == NERFX_PREC_BF16 ? WOperand<NERFX_PREC_BF16>::CHUNK : WOperand<NERFX_PREC_FP32>::CHUNK; }
 
 int wgrad_tasks_create(nerfx_model* m) {
     for (int prec = 0; prec < 2; ++prec) {
@@ -233,30 +296,40 @@ int wgrad_tasks_create(nerfx_model* m) {
 }
 
 int64_t wgrad_partial_bytes(const nerfx_model* m, int prec, uint64_t m_pad) {
-    int n_split; uint32_t kps;
-    split_plan(m->n_wtasks[prec], m_pad, n_split, kps);
-    return (int64_t)n_split * m->n_wtasks[prec] * 4096 * (int64_t)sizeof(float);
+    int n_split, cps;
+    split_plan(m->n_wtasks[prec], (int)(m_pad / chunk_samples(prec)), n_split, cps);
+    return (int64_t)n_split * m->n_wtasks[prec] * (WG_SIDE * WG_SIDE * 1024) * (int64_t)sizeof(float);
 }
 
 template <int PREC>
 static int launch_wgrad_prec(const nerfx_model* m, uint64_t m_pad, const void* ztape, const void* gtape, float* partial,
                              const GradList& grads, hipStream_t stream) {
-    using T = typename WOperand<PREC>::T;
-    const int n_tasks = m->n_wtasks[PREC];
-    int n_split; uint32_t kps;
-    split_plan(n_tasks, m_pad, n_split, kps);
+    using O = WOperand<PREC>;
+    using T = typename O::T;
+    const int n_tasks = m->n_wtasks[PREC], n_chunks = (int)(m_pad / O::CHUNK);
+    int n_split, cps;
+    split_plan(n_tasks, n_chunks, n_split, cps);
     const WTask* tasks = (const WTask*)m->wtasks_dev[PREC];
-    const int waves = n_tasks * n_split, grid = (waves + 3) / 4;
-#define NERFX_WGRAD(ACT_) \
-    hipLaunchKernelGGL((wgrad_kernel<PREC, ACT_>), dim3(grid), dim3(256), 0, stream, tasks, n_tasks, n_split, kps, \
-                       (uint32_t)m_pad, (const T*)ztape, (const T*)gtape, partial)
+    const size_t lds = 2 * 2 * WG_SIDE * O::CHUNK * 32 * sizeof(T);          // 64 KiB: two buffers of 8 tiles
+#define NERFX_WGRAD(ACT_)                                                                                         \
+    do {                                                                                                          \
+        auto kern = wgrad_kernel<PREC, ACT_>;                                                                     \
+        static thread_local bool configured = false;                                                              \
+        if (!configured) {                                                                                        \
+            NERFX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            configured = true;                                                                                    \
+        }                                                                                                         \
+        hipLaunchKernelGGL(kern, dim3(n_tasks * n_split), dim3(256), lds, stream, tasks, n_tasks, cps, n_chunks,   \
+                           m_pad, (const T*)ztape, (const T*)gtape, partial);                                      \
+    } while (0)
     switch (m->plan[PREC].desc.activ) {
         case NERFX_ACT_RELU: NERFX_WGRAD(NERFX_ACT_RELU); break;
         case NERFX_ACT_LEAKY_RELU: NERFX_WGRAD(NERFX_ACT_LEAKY_RELU); break;
         default: NERFX_WGRAD(NERFX_ACT_SILU); break;
     }
 #undef NERFX_WGRAD
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(n_tasks * 16), dim3(256), 0, stream, tasks, n_tasks, n_split, partial, grads);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(n_tasks * (WG_SIDE * WG_SIDE * 1024 / 256)), dim3(256), 0, stream, tasks,
+                       n_tasks, n_split, partial, grads);
     return launch_status("wgrad kernels");
 }
 

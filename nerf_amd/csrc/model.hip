@@ -69,14 +69,13 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
         unit += units_of(L);
     }
     p.bwd_units = unit;
-    // tape rows
-    int row = 0;
-    p.tape_ex_row = row; row += ex_units * slots_per_unit(prec);
-    p.tape_ed_row = row; row += ed_units * slots_per_unit(prec);
-    for (int li = 0; li < p.n_layers - 1; ++li) { p.tape_z_row[li] = row; row += 32 * p.layer[li].n_tiles; }
-    p.tape_go_row = p.tape_z_row[p.n_layers - 1] = row; row += 4;
-    p.tape_gs_row = row; row += 4;
-    p.tape_rows = row;
+    // tape tiles
+    int tile = 0;
+    p.tape_ex_tile = tile; tile += ex_units * slots_per_unit(prec) / 32;
+    p.tape_ed_tile = tile; tile += ed_units * slots_per_unit(prec) / 32;
+    for (int li = 0; li < p.n_layers - 1; ++li) { p.tape_z_tile[li] = tile; tile += p.layer[li].n_tiles; }
+    p.tape_heads_tile = p.tape_z_tile[p.n_layers - 1] = tile; tile += 1;
+    p.tape_tiles = tile;
     p.sigw_off = p.n_layers * BIAS_STRIDE;
     p.sigb_off = p.sigw_off + BIAS_STRIDE;
     auto table_floats = [](int kind, int n) { return 4 * enc_pair_slots(kind, n); };
