@@ -10,6 +10,8 @@ int launch_mlp_bf16_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
 int launch_mlp_fp32_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_train(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_fp32_train(int activ, int wt, const MlpArgs& a, hipStream_t s);
+int launch_mlp_bf16_train_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
+int launch_mlp_fp32_train_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bwd_bf16(int activ, int wt, const BwdArgs& a, hipStream_t s);
 int launch_mlp_bwd_fp32(int activ, int wt, const BwdArgs& a, hipStream_t s);
 int64_t wgrad_partial_bytes(const nerfx_model* m, int prec, uint64_t m_pad);
@@ -53,6 +55,9 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
         a.n_blocks = (uint32_t)(a.tape_m_pad / (32 * waves));       // pad columns are written too
         a.tape_ex_tile = p.tape_ex_tile; a.tape_ed_tile = p.tape_ed_tile;
         for (int li = 0; li < p.n_layers; ++li) a.tape_z_tile[li] = p.tape_z_tile[li];
+        const bool small_enc = a.ex_units <= ENC_BLOCK && a.ed_units <= ENC_BLOCK;
+        if (small_enc && p.wt == 8 && p.desc.resid && (p.hd == 2 || p.hd == 4))
+            return (precision == NERFX_PREC_BF16 ? launch_mlp_bf16_train_fixed : launch_mlp_fp32_train_fixed)(p.desc.activ, p.hd, a, (hipStream_t)stream);
         return (precision == NERFX_PREC_BF16 ? launch_mlp_bf16_train : launch_mlp_fp32_train)(p.desc.activ, p.wt, a, (hipStream_t)stream);
     }
     // encoders that fit the kernels' register cache take the fast instantiations

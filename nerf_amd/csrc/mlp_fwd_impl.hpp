@@ -523,7 +523,6 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
 // TRAIN: also record the tape the backward kernels read (pre-activations and encodings).
 template <int PREC, int WT, class RG, int ACT, bool BIGENC, int HD, bool TRAIN = false>
 __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) void mlp_fwd_kernel(const MlpArgs a) {
-    static_assert(!TRAIN || (BIGENC && HD == 0), "the training forward uses the general encoder / depth paths");
     constexpr int WAVES = RG::WAVES;
     using P = Prec<PREC>;
     using Frag = typename P::Frag;
@@ -578,6 +577,13 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         // in registers, (re)built right before each consuming layer.
         Encoding<PREC> enc;
         enc.template prepare<BIGENC>(a.ex_kind, a.ex_units, cst + a.tabx_off, h, px, py, pz);
+        Tape<PREC> tape{(typename Tape<PREC>::T*)a.tape, a.tape_m_pad, m};   // m < m_pad also for tail lanes
+        const Tape<PREC>* zt = TRAIN ? &tape : nullptr;
+        if constexpr (TRAIN && !BIGENC) {                           // wide encoders are recorded where they are evaluated
+#pragma unroll
+            for (int u = 0; u < ENC_BLOCK; ++u)
+                if (u < a.ex_units) tape.store_enc(a.tape_ex_tile, u, h, enc.cached[u]);
+        }
         uint32_t stash = 0;
         if constexpr (STASH) {
 #pragma unroll
@@ -589,8 +595,6 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         st.mark(ST_ENCODE);
         Frag A[HN], B[HN];                                        // ping-pong activation fragments
         float dot = 0.0f;
-        Tape<PREC> tape{(typename Tape<PREC>::T*)a.tape, a.tape_m_pad, m};   // m < m_pad also for tail lanes
-        const Tape<PREC>* zt = TRAIN ? &tape : nullptr;
         // ---- fc_1 then fc_2; fc_2's first layer optionally sees [phi_x | h] (model.py:71-73).
         // Layer 0 writes A; the remaining 2 hd - 1 trunk layers alternate A -> B, B -> A, so the
         // last one always lands in B.
@@ -633,6 +637,11 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
             ++li;
             // ---- rgb.0 on [phi_d | features] (model.py:53, :76): A -> B ---------------------
             { st.mark(ST_EPILOGUE); enc.template prepare<BIGENC>(a.ed_kind, a.ed_units, cst + a.tabd_off, h, dx, dy, dz); st.mark(ST_ENCODE); }
+            if constexpr (TRAIN && !BIGENC) {
+#pragma unroll
+                for (int u = 0; u < ENC_BLOCK; ++u)
+                    if (u < a.ed_units) tape.store_enc(a.tape_ed_tile, u, h, enc.cached[u]);
+            }
             linear<PREC, RG, ACT, BIGENC, RT, WT, false, false, TRAIN>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li], a.tape_ed_tile);
             ++li;
             // ---- rgb.2 + widened sigmoid (model.py:54, activations.py:18-20) ----------------
@@ -685,11 +694,11 @@ static int launch_width(int wt, const MlpArgs& a, hipStream_t s) {
 }
 
 // Width-256 models with the skip connection and depth 4 or 8 (the reference's configurations).
-template <int PREC, class RG>
+template <int PREC, class RG, bool TRAIN = false>
 static int launch_fixed_depth(int activ, int hd, const MlpArgs& a, hipStream_t s) {
 #define NERFX_FIXED(ACT_)                                                                  \
     case ACT_:                                                                             \
-        return hd == 2 ? launch_cfg<PREC, 8, RG, ACT_, false, 2>(a, s) : launch_cfg<PREC, 8, RG, ACT_, false, 4>(a, s);
+        return hd == 2 ? launch_cfg<PREC, 8, RG, ACT_, false, 2, TRAIN>(a, s) : launch_cfg<PREC, 8, RG, ACT_, false, 4, TRAIN>(a, s);
     switch (activ) {
         NERFX_FIXED(NERFX_ACT_RELU)
         NERFX_FIXED(NERFX_ACT_LEAKY_RELU)
