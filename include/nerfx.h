@@ -88,6 +88,10 @@ int  nerfx_model_create(const nerfx_model_desc_t* desc /* host */,
                         void* stream, nerfx_model_t** out /* host */);
 int  nerfx_model_refresh(nerfx_model_t* model, const float* const* tensors, int n_tensors,
                          void* stream);
+/* The same for the packed copies of ONE precision (NERFX_PREC_*) plus the shared
+ * constants: what a training loop that stays in one precision needs per step. */
+int  nerfx_model_refresh_precision(nerfx_model_t* model, const float* const* tensors, int n_tensors,
+                                   int precision, void* stream);
 void nerfx_model_destroy(nerfx_model_t* model);
 
 /* ---- K1: stratified sampling + encoding (standalone form) ----------------

@@ -33,6 +33,7 @@ SIGNATURES = {
     "nerfx_device_info": (_i, [_i, C.POINTER(DeviceInfo)]),
     "nerfx_model_create": (_i, [C.POINTER(ModelDesc), C.POINTER(_p), _i, _p, C.POINTER(_p)]),
     "nerfx_model_refresh": (_i, [_p, C.POINTER(_p), _i, _p]),
+    "nerfx_model_refresh_precision": (_i, [_p, C.POINTER(_p), _i, _i, _p]),
     "nerfx_model_destroy": (None, [_p]),
     "nerfx_sample_encode_fwd": (_i, [_p, _p, _l, _f, _f, _i, _p, _i, _i, _p, _i, _i, _p,
                                      _p, _p, _p, _p, _p, _p]),

@@ -149,6 +149,7 @@ struct nerfx_model {
     nerfx::ModelPlan plan[2];          // indexed by NERFX_PREC_*
     void* stream_dev[2];               // packed unit streams
     void* stream_bwd_dev[2];           // packed backward (transposed) unit streams
+    nerfx::LayerPlan* plans_dev[2];    // forward then backward layer plans (read by the pack kernel)
     void* wtasks_dev[2];               // weight-gradient task tables (mlp_wgrad.hip)
     int n_wtasks[2];
     float* const_dev;                  // const block (same for both precisions)

@@ -87,8 +87,7 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
 
 // One thread per packed 16-byte lane slice of one layer (padding units included).
 template <int PREC>
-__global__ __launch_bounds__(256) void pack_layer_kernel(const float* __restrict__ W, LayerPlan L,
-                                                         void* __restrict__ stream) {
+__device__ __forceinline__ void pack_layer(const float* __restrict__ W, const LayerPlan& L, void* __restrict__ stream) {
     constexpr int EPL = PREC == NERFX_PREC_BF16 ? 8 : 4;          // elements per lane per unit
     const int group_units = L.enc_seg + L.chain_seg;
     const int64_t n_slices = (int64_t)units_of(L) * 64;
@@ -142,9 +141,23 @@ __global__ __launch_bounds__(256) void pack_layer_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void pack_vector_kernel(const float* __restrict__ src, int n, int cap,
-                                                          float* __restrict__ dst) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < cap; i += gridDim.x * 256) dst[i] = i < n ? src[i] : 0.0f;
+struct PackSources { const float* w[2 * MAX_LAYERS]; };
+
+// All layers of both streams of one precision in one launch: blockIdx.y picks the layer plan
+// (forward layers first, then the backward chain's), blockIdx.x strides over its 16-byte slices.
+template <int PREC>
+__global__ __launch_bounds__(256) void pack_streams_kernel(const LayerPlan* __restrict__ plans, int n_fwd, PackSources src,
+                                                           void* __restrict__ fwd, void* __restrict__ bwd) {
+    const LayerPlan L = plans[blockIdx.y];
+    pack_layer<PREC>(src.w[blockIdx.y], L, blockIdx.y < n_fwd ? fwd : bwd);
+}
+
+struct VectorJobs { const float* src[MAX_LAYERS + 2]; int n[MAX_LAYERS + 2], cap[MAX_LAYERS + 2], off[MAX_LAYERS + 2]; };
+
+// Biases, density-head weights and bias into the const block: blockIdx.y picks the vector.
+__global__ __launch_bounds__(256) void pack_vectors_kernel(VectorJobs jobs, float* __restrict__ consts) {
+    const int j = blockIdx.y;
+    for (int i = threadIdx.x; i < jobs.cap[j]; i += 256) consts[jobs.off[j] + i] = i < jobs.n[j] ? jobs.src[j][i] : 0.0f;
 }
 
 // Pair-coefficient table of one encoder (see enc_pair_slots): entry k = (cx, cy, cz, 0).
@@ -176,32 +189,33 @@ static int tensor_index(const ModelPlan& p, int li, bool bias) {
     return base + (bias ? 1 : 0);
 }
 
-static int pack_all(nerfx_model* m, const float* const* tensors, hipStream_t stream) {
+// Packs the const block and the unit streams of the precisions in `mask` (bit NERFX_PREC_*).
+static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipStream_t stream) {
     const ModelPlan& p0 = m->plan[0];
     const nerfx_model_desc_t& d = p0.desc;
     for (int i = 0; i < m->n_tensors; ++i) NERFX_REQUIRE(tensors[i] != nullptr, "tensor %d is NULL", i);
     for (int prec = 0; prec < 2; ++prec) {
+        if (!(mask >> prec & 1)) continue;
         const ModelPlan& p = m->plan[prec];
-        for (int li = 0; li < p.n_layers + p.n_bwd; ++li) {
-            const bool bwd = li >= p.n_layers;
-            const LayerPlan& L = bwd ? p.bwd[li - p.n_layers] : p.layer[li];
-            void* dst = bwd ? m->stream_bwd_dev[prec] : m->stream_dev[prec];
-            const int64_t slices = (int64_t)units_of(L) * 64;
-            const int grid = (int)std::min<int64_t>((slices + 255) / 256, 4096);
-            const float* W = tensors[tensor_index(p, bwd ? L.src_layer : li, false)];
-            if (prec == NERFX_PREC_BF16)
-                hipLaunchKernelGGL(pack_layer_kernel<NERFX_PREC_BF16>, dim3(grid), dim3(256), 0, stream, W, L, dst);
-            else
-                hipLaunchKernelGGL(pack_layer_kernel<NERFX_PREC_FP32>, dim3(grid), dim3(256), 0, stream, W, L, dst);
-        }
+        PackSources src{};
+        for (int li = 0; li < p.n_layers + p.n_bwd; ++li)
+            src.w[li] = tensors[tensor_index(p, li >= p.n_layers ? p.bwd[li - p.n_layers].src_layer : li, false)];
+        const dim3 grid(64, p.n_layers + p.n_bwd);
+        if (prec == NERFX_PREC_BF16)
+            hipLaunchKernelGGL(pack_streams_kernel<NERFX_PREC_BF16>, grid, dim3(256), 0, stream, m->plans_dev[prec], p.n_layers, src,
+                               m->stream_dev[prec], m->stream_bwd_dev[prec]);
+        else
+            hipLaunchKernelGGL(pack_streams_kernel<NERFX_PREC_FP32>, grid, dim3(256), 0, stream, m->plans_dev[prec], p.n_layers, src,
+                               m->stream_dev[prec], m->stream_bwd_dev[prec]);
     }
-    auto vec = [&](const float* src, int n, int cap, int off) {
-        hipLaunchKernelGGL(pack_vector_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, src, n, cap, m->const_dev + off);
-    };
+    VectorJobs jobs{};
+    int nj = 0;
+    auto vec = [&](const float* src, int n, int cap, int off) { jobs.src[nj] = src; jobs.n[nj] = n; jobs.cap[nj] = cap; jobs.off[nj] = off; ++nj; };
     for (int li = 0; li < p0.n_layers; ++li)
         vec(tensors[tensor_index(p0, li, true)], p0.layer[li].out_dim, BIAS_STRIDE, li * BIAS_STRIDE);
     vec(tensors[2 + 4 * p0.hd], d.width, BIAS_STRIDE, p0.sigw_off);
     vec(tensors[2 + 4 * p0.hd + 1], 1, 4, p0.sigb_off);
+    hipLaunchKernelGGL(pack_vectors_kernel, dim3(1, nj), dim3(256), 0, stream, jobs, m->const_dev);
     auto table = [&](const float* src, int kind, int n, int off) {
         const int entries = enc_pair_slots(kind, n);
         hipLaunchKernelGGL(pack_pair_table_kernel, dim3((entries + 255) / 256), dim3(256), 0, stream, src, kind, n, entries,
@@ -240,8 +254,20 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
         nerfx_model_destroy(m);
         return fail(e == hipErrorOutOfMemory ? NERFX_E_NOMEM : NERFX_E_HIP, "model allocation failed: %s", hipGetErrorString(e));
     }
+    for (int prec = 0; prec < 2 && e == hipSuccess; ++prec) {           // the layer plans the pack kernel reads
+        const ModelPlan& p = m->plan[prec];
+        LayerPlan all[2 * MAX_LAYERS];
+        for (int li = 0; li < p.n_layers + p.n_bwd; ++li) all[li] = li < p.n_layers ? p.layer[li] : p.bwd[li - p.n_layers];
+        const size_t bytes = (size_t)(p.n_layers + p.n_bwd) * sizeof(LayerPlan);
+        e = hipMalloc((void**)&m->plans_dev[prec], bytes);
+        if (e == hipSuccess) e = hipMemcpy(m->plans_dev[prec], all, bytes, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        nerfx_model_destroy(m);
+        return fail(NERFX_E_HIP, "model set-up failed: %s", hipGetErrorString(e));
+    }
     if (int rc = wgrad_tasks_create(m)) { nerfx_model_destroy(m); return rc; }
-    if (int rc = pack_all(m, tensors, (hipStream_t)stream)) { nerfx_model_destroy(m); return rc; }
+    if (int rc = pack_all(m, tensors, 3, (hipStream_t)stream)) { nerfx_model_destroy(m); return rc; }
     *out = m;
     return 0;
 }
@@ -249,7 +275,15 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
 extern "C" int nerfx_model_refresh(nerfx_model_t* m, const float* const* tensors, int n_tensors, void* stream) {
     NERFX_REQUIRE(m && tensors, "NULL argument");
     NERFX_REQUIRE(n_tensors == m->n_tensors, "expected %d tensors, got %d", m->n_tensors, n_tensors);
-    return pack_all(m, tensors, (hipStream_t)stream);
+    return pack_all(m, tensors, 3, (hipStream_t)stream);
+}
+
+extern "C" int nerfx_model_refresh_precision(nerfx_model_t* m, const float* const* tensors, int n_tensors, int precision,
+                                             void* stream) {
+    NERFX_REQUIRE(m && tensors, "NULL argument");
+    NERFX_REQUIRE(n_tensors == m->n_tensors, "expected %d tensors, got %d", m->n_tensors, n_tensors);
+    NERFX_REQUIRE(precision == NERFX_PREC_FP32 || precision == NERFX_PREC_BF16, "unknown precision %d", precision);
+    return pack_all(m, tensors, 1 << precision, (hipStream_t)stream);
 }
 
 extern "C" void nerfx_model_destroy(nerfx_model_t* m) {
@@ -260,6 +294,8 @@ extern "C" void nerfx_model_destroy(nerfx_model_t* m) {
         if (m->stream_bwd_dev[prec]) (void)hipFree(m->stream_bwd_dev[prec]);
     for (int prec = 0; prec < 2; ++prec)
         if (m->wtasks_dev[prec]) (void)hipFree(m->wtasks_dev[prec]);
+    for (int prec = 0; prec < 2; ++prec)
+        if (m->plans_dev[prec]) (void)hipFree(m->plans_dev[prec]);
     if (m->const_dev) (void)hipFree(m->const_dev);
     delete m;
 }

@@ -194,11 +194,10 @@ class ModelHandle:
         if self.device.type != "cuda":
             raise RuntimeError(f"nerf_amd runs on ROCm devices only: the model is on {self.device}")
         self._ptr = C.c_void_p()
-        self._stamp = None
         tensors, arr = self._gather()
         with torch.cuda.device(self.device):
             check(lib.nerfx_model_create(C.byref(self.desc), arr, len(tensors), _stream(), C.byref(self._ptr)))
-        self._stamp = self._current_stamp()
+        self._stamp = [self._current_stamp()] * 2                   # per precision: create packs both
 
     def _gather(self):
         tensors = [_dev(t.detach(), "weight") for t in self._sources]
@@ -208,15 +207,16 @@ class ModelHandle:
     def _current_stamp(self):
         return tuple((t.data_ptr(), t._version) for t in self._sources)
 
-    def sync(self) -> "ModelHandle":
-        """Re-pack if any source tensor was written (optimizer step, load_state_dict)."""
+    def ready(self, prec: int):
+        """The handle, with the packed copies of precision `prec` brought up to date if any
+        source tensor was written since they were packed (optimizer step, load_state_dict)."""
         stamp = self._current_stamp()
-        if stamp != self._stamp:
+        if stamp != self._stamp[prec]:
             tensors, arr = self._gather()
             with torch.cuda.device(self.device):
-                check(lib.nerfx_model_refresh(self._ptr, arr, len(tensors), _stream()))
-            self._stamp = stamp
-        return self
+                check(lib.nerfx_model_refresh_precision(self._ptr, arr, len(tensors), prec, _stream()))
+            self._stamp[prec] = stamp
+        return self._ptr
 
     @property
     def ptr(self):
@@ -240,7 +240,7 @@ def handle_for(module) -> ModelHandle:
     if h is None or h.device != dev:
         h = ModelHandle(module)
         _HANDLES[module] = h
-    return h.sync()
+    return h
 
 
 # ---- MLP --------------------------------------------------------------------------------
@@ -251,7 +251,8 @@ def mlp_points(handle: ModelHandle, x: Tensor, d: Tensor, density_only: bool = F
     sigma = torch.empty((M,), device=x.device)
     rgb = None if density_only else torch.empty((M, 3), device=x.device)
     with torch.cuda.device(x.device):
-        check(lib.nerfx_mlp_fwd_points(handle.ptr, precision() if prec is None else prec, _p(x), _p(d), M,
+        prec = precision() if prec is None else prec
+        check(lib.nerfx_mlp_fwd_points(handle.ready(prec), prec, _p(x), _p(d), M,
                                        _p(sigma), _p(rgb), _stream()))
     return sigma, rgb
 
@@ -263,7 +264,8 @@ def mlp_rays(handle: ModelHandle, ro: Tensor, rd: Tensor, t: Tensor, density_onl
     sigma = torch.empty((B, n), device=t.device)
     rgb = None if density_only else torch.empty((B, n, 3), device=t.device)
     with torch.cuda.device(t.device):
-        check(lib.nerfx_mlp_fwd_rays(handle.ptr, precision() if prec is None else prec, _p(ro), _p(rd), _p(t), B, n,
+        prec = precision() if prec is None else prec
+        check(lib.nerfx_mlp_fwd_rays(handle.ready(prec), prec, _p(ro), _p(rd), _p(t), B, n,
                                      _p(sigma), _p(rgb), _stream()))
     return sigma, rgb
 
@@ -315,8 +317,9 @@ def render(coarse: ModelHandle, fine: Optional[ModelHandle], ro: Tensor, rd: Ten
     ws_bytes = lib.nerfx_render_workspace_bytes(B, nc, nf)
     ws = torch.empty((max(ws_bytes, 1),), device=dev, dtype=torch.uint8)
     with torch.cuda.device(dev):
-        check(lib.nerfx_render_fwd(coarse.ptr, None if fine is None else fine.ptr,
-                                   precision() if prec is None else prec, _p(ro), _p(rd), B, tn, tf, nc, nf,
+        prec = precision() if prec is None else prec
+        check(lib.nerfx_render_fwd(coarse.ready(prec), None if fine is None else fine.ready(prec),
+                                   prec, _p(ro), _p(rd), B, tn, tf, nc, nf,
                                    _p(u_c), _p(u_f), _p(ws), ws_bytes, _p(t), _p(w), _p(depth), _p(rgb_map), _stream()))
     return t, w, depth, rgb_map
 
@@ -348,6 +351,7 @@ class _FieldFunction(torch.autograd.Function):
             M, shape_s, shape_c = t.numel(), tuple(t.shape), (*t.shape, 3)
         sigma = torch.empty(shape_s, device=dev)
         rgb = torch.empty(shape_c, device=dev)
+        handle.ready(prec)
         ws_bytes = lib.nerfx_mlp_train_workspace_bytes(handle.ptr, prec, M)
         if ws_bytes < 0:
             raise _lib.NerfxError("nerfx_mlp_train_workspace_bytes rejected its arguments")
