@@ -5,6 +5,9 @@ There is no CPU fallback: if the library is missing the import fails loudly.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- first: libnerfx.so must bind to the HIP runtime torch has loaded, so that
+#                               torch's streams and device pointers are valid inside the library
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NERFX_LIB", os.path.join(_HERE, "libnerfx.so"))   # override: diagnostic builds
 

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WTask* __restri
 
 // Sample splits for a launch: enough workgroups to fill the device twice over.
 static void split_plan(int n_tasks, int n_chunks, int& n_split, int& chunks_per_split) {
+    if (n_chunks <= 0 || n_tasks <= 0) { n_split = 0; chunks_per_split = 1; return; }
     int want = (2048 + n_tasks - 1) / n_tasks;
     want = std::max(1, std::min(want, n_chunks));
     chunks_per_split = (n_chunks + want - 1) / want;

@@ -375,3 +375,75 @@ def test_render_oracle_2048_rays_and_properties(ops):
         assert torch.equal(a, c)
     assert bool((full[0][:, 1:] >= full[0][:, :-1]).all())
     assert_close(full[1].sum(-1).cpu(), torch.ones(100_000), rtol=0, atol=1e-4, what="sum of weights")
+
+
+def test_full_frame_properties_bf16_and_fp32(ops):
+    """The benchmark's own size (800 x 800 = 640,000 rays, 64 + 64 samples): properties that do
+    not need the oracle.  One call == the same frame in 65,536-ray calls, bit for bit (rays are
+    independent); reruns identical; t ascending; weights in [0, 1] summing to 1 (the last
+    segment is 1e10 long, so every ray is opaque in the end); bf16 within 1e-2 of fp32 on rgb."""
+    from nerf_amd.core import BoundedVolumeRaymarcher, NeRF, PositionalEncoding
+    torch.manual_seed(0)
+    model = NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 6), 256, 4).cuda()
+    bvr = BoundedVolumeRaymarcher(2.0, 6.0, 64, 64)
+    n = 800 * 800
+    g = torch.Generator(device="cuda").manual_seed(0)
+    ro, rd = torch.rand(n, 3, device="cuda", generator=g), torch.rand(n, 3, device="cuda", generator=g)
+    out = {}
+    for prec in ("fp32", "bf16"):
+        ops.set_precision(prec)
+        with torch.no_grad():
+            whole = bvr.render_volume(model, model, ro, rd)
+            parts = [bvr.render_volume(model, model, ro[s:s + 65536], rd[s:s + 65536]) for s in range(0, n, 65536)]
+        for k in range(4):
+            assert torch.equal(whole[k], torch.cat([p[k] for p in parts])), f"{prec}: output {k} depends on batching"
+        t, w, depth, rgb = whole
+        assert bool((t[:, 1:] >= t[:, :-1]).all()) and float(t.min()) >= 2.0 and float(t.max()) <= 6.0
+        assert bool((w >= 0).all()) and bool((w <= 1).all())
+        assert float((w.sum(-1) - 1).abs().max()) < 1e-4
+        assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(depth).all())
+        assert float(rgb.min()) >= -0.001 - 1e-6 and float(rgb.max()) <= 1.001 + 1e-6
+        assert float((depth - (w * t).sum(-1)).abs().max()) < 1e-4
+        out[prec] = rgb
+    ops.set_precision(None)
+    assert float((out["bf16"] - out["fp32"]).abs().max()) < 1e-2
+
+
+def test_empty_and_single_ray(ops):
+    """Zero rays and one ray go through every entry point of the render path."""
+    from nerf_amd.core import BoundedVolumeRaymarcher
+    meta, g = load_golden("g3_mlp_student")
+    model = product_model(meta, g)
+    bvr = BoundedVolumeRaymarcher(2.0, 6.0, 8, 8)
+    empty = torch.zeros(0, 3, device="cuda")
+    t, w, depth, rgb = bvr.render_volume(model, model, empty, empty)
+    assert t.shape == (0, 16) and w.shape == (0, 16) and depth.shape == (0,) and rgb.shape == (0, 3)
+    sigma, colour = model(empty, empty)
+    assert sigma.shape == (0,) and colour.shape == (0, 3)
+    one = torch.rand(1, 3, device="cuda")
+    t, w, depth, rgb = bvr.render_volume(model, model, one, one)
+    om = oracle_model(meta, g)
+    ref = O.render_volume(om, om, one.cpu(), one.cpu(), 2.0, 6.0, 8, 8)
+    ops.set_precision("fp32")
+    t, w, depth, rgb = bvr.render_volume(model, model, one, one)
+    ops.set_precision(None)
+    assert_close(rgb.cpu(), ref[3].detach(), rtol=1e-5, atol=1e-5, what="single ray rgb")
+
+
+def test_non_finite_inputs_poison_only_their_ray(ops):
+    """A NaN origin makes that ray's outputs NaN (as it would through the reference's MLP) and
+    leaves the other rays untouched."""
+    from nerf_amd.core import BoundedVolumeRaymarcher
+    meta, g = load_golden("g3_mlp_student")
+    model = product_model(meta, g)
+    bvr = BoundedVolumeRaymarcher(2.0, 6.0, 16, 16)
+    gen = torch.Generator().manual_seed(9)
+    ro, rd = torch.rand(70, 3, generator=gen).cuda(), torch.rand(70, 3, generator=gen).cuda()
+    clean = bvr.render_volume(model, model, ro, rd)
+    ro2 = ro.clone()
+    ro2[33, 1] = float("nan")
+    dirty = bvr.render_volume(model, model, ro2, rd)
+    keep = torch.ones(70, dtype=torch.bool, device="cuda")
+    keep[33] = False
+    assert torch.equal(clean[3][keep], dirty[3][keep]) and torch.equal(clean[2][keep], dirty[2][keep])
+    assert bool(torch.isnan(dirty[3][33]).all())
