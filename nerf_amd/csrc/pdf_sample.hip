@@ -2,8 +2,8 @@
 //
 // One 64-lane wavefront owns one ray: interior coarse weights -> pdf -> cdf by a
 // wave scan, `searchsorted(right=True)` by binary search in LDS, the lerp of
-// ray.py:182-186, then the nc + nf values are put in ascending order (rank
-// merge when the fine samples are already ascending, bitonic sort otherwise).
+// ray.py:182-186, then the nc + nf values are put in ascending order (rank merge seeded by the
+// bin indices when the fine samples are already ascending, bitonic sort otherwise).
 #include "common.hpp"
 
 namespace nerfx {
@@ -49,17 +49,39 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
     const float* __restrict__ u_g, float* __restrict__ t_sorted, float* __restrict__ cdf_out,
     int64_t* __restrict__ idx_out, float* __restrict__ t_pdf_out) {
     __shared__ float tc[K4_MAX], cdf[K4_MAX], bins[K4_MAX], tp[K4_MAX], srt[K4_SORT];
+    __shared__ int guess[K4_MAX], hist[K4_MAX + 1];
     __shared__ int unsorted;
     const int lane = threadIdx.x;
     const int nb = nc - 1;                         // bins (mid points) and cdf entries
     const int nw = nc - 2;                         // interior weights
+    // The per-ray work is a chain of dependent steps, so a wavefront hides HBM latency only by
+    // loading the NEXT ray's inputs (registers) before it starts on the current one.
+    constexpr int R = K4_MAX / 64;
+    float t_cur[R], w_cur[R], u_cur[R], t_nxt[R], w_nxt[R], u_nxt[R];
+    auto fetch = [&](int64_t ray, float (&tr)[R], float (&wr)[R], float (&ur)[R]) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int i = lane + 64 * q;
+            tr[q] = i < nc ? t_c[ray * nc + i] : 0.f;
+            wr[q] = i < nc ? w_c[ray * nc + i] : 0.f;
+            ur[q] = (u_g && i < nf) ? u_g[ray * nf + i] : 0.f;
+        }
+    };
+    if ((int64_t)blockIdx.x < n_rays) fetch(blockIdx.x, t_nxt, w_nxt, u_nxt);
     for (int64_t ray = blockIdx.x; ray < n_rays; ray += gridDim.x) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) { t_cur[q] = t_nxt[q]; w_cur[q] = w_nxt[q]; u_cur[q] = u_nxt[q]; }
+        if (ray + gridDim.x < n_rays) fetch(ray + gridDim.x, t_nxt, w_nxt, u_nxt);
         // -- pdf and cdf (ray.py:161-164, :220) --------------------------------
         float part = 0.f;
-        for (int i = lane; i < nc; i += 64) {
-            const float t = t_c[ray * nc + i];
-            tc[i] = t;
-            if (i >= 1 && i <= nw) part += __fadd_rn(w_c[ray * nc + i], 1e-5f);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int i = lane + 64 * q;
+            if (i < nc) {
+                tc[i] = t_cur[q];
+                srt[i] = __fadd_rn(w_cur[q], 1e-5f);                     // weights + 1e-5, read back shifted by one
+                if (i >= 1 && i <= nw) part += srt[i];
+            }
         }
         if (lane == 0) unsorted = 0;
 #pragma unroll
@@ -69,7 +91,7 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
         double carry = 0.0;
         for (int k0 = 0; k0 < nw; k0 += 64) {      // cdf[k + 1] = sum_{j <= k} pdf_j
             const int k = k0 + lane;
-            const float pdf = k < nw ? __fadd_rn(w_c[ray * nc + k + 1], 1e-5f) / total : 0.f;
+            const float pdf = k < nw ? srt[k + 1] / total : 0.f;
             const double inc = wave_incl_sum((double)pdf, lane) + carry;
             if (k < nw) cdf[k + 1] = (float)inc;
             carry = __shfl(inc, 63, 64);
@@ -80,8 +102,11 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
         if (cdf_out)
             for (int i = lane; i < nb; i += 64) cdf_out[ray * nb + i] = cdf[i];
         // -- inverse cdf (ray.py:166-186) ---------------------------------------
-        for (int j = lane; j < nf; j += 64) {
-            const float u = u_g ? u_g[ray * nf + j] : linspace_at(0.f, 1.f, nf, j);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int j = lane + 64 * q;
+            if (j >= nf) continue;
+            const float u = u_g ? u_cur[q] : linspace_at(0.f, 1.f, nf, j);
             const int idx = upper_bound(cdf, nb, u);
             const int below = max(idx - 1, 0), above = min(idx, nw);
             const float cb = cdf[below], ca = cdf[above], bb = bins[below], ba = bins[above];
@@ -90,6 +115,7 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
             const float frac = __fsub_rn(u, cb) / den;
             const float t = __fadd_rn(bb, __fmul_rn(frac, __fsub_rn(ba, bb)));
             tp[j] = t;
+            guess[j] = idx;
             if (idx_out) idx_out[ray * nf + j] = idx;
             if (t_pdf_out) t_pdf_out[ray * nf + j] = t;
         }
@@ -103,9 +129,36 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
         const int n = nc + nf;
         float* out = t_sorted + ray * n;
         if (!unsorted) {
-            // both runs ascending: final slot = own index + rank in the other run
-            for (int i = lane; i < nc; i += 64) out[i + lower_bound(tp, nf, tc[i])] = tc[i];
-            for (int j = lane; j < nf; j += 64) out[j + upper_bound(tc, nc, tp[j])] = tp[j];
+            // Both runs ascending: final slot = own index + rank in the other run.
+            // Fine sample j came out of bin idx_j, i.e. it lies between the mid points around
+            // tc[idx_j], so its rank among the coarse values, r_j = #{i : tc[i] <= tp[j]}, is idx_j
+            // or idx_j + 1: start there and let two short scans settle ties and roundings.
+            // The coarse values then fill the slots left over: tc[i] goes to i + #{j : r_j <= i},
+            // a histogram of r followed by a running sum.
+            for (int i = lane; i <= nc; i += 64) hist[i] = 0;
+            __syncthreads();
+            for (int j = lane; j < nf; j += 64) {
+                const float v = tp[j];
+                int r = min(guess[j], nc);
+                while (r < nc && tc[r] <= v) ++r;
+                while (r > 0 && tc[r - 1] > v) --r;
+                out[j + r] = v;
+                atomicAdd(&hist[r], 1);
+            }
+            __syncthreads();
+            int carry = 0;                                           // #{j : r_j <= i}: inclusive running sum of hist
+            for (int i0 = 0; i0 < nc; i0 += 64) {
+                const int i = i0 + lane;
+                int inc = i < nc ? hist[i] : 0;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(inc, off, 64);
+                    if (lane >= off) inc += o;
+                }
+                inc += carry;
+                if (i < nc) out[i + inc] = tc[i];
+                carry = __shfl(inc, 63, 64);
+            }
         } else {
             int p2 = 1;
             while (p2 < n) p2 <<= 1;
