@@ -166,7 +166,12 @@ struct WeightRing {
                                              (void __attribute__((address_space(3)))*)l, 16, 0, 0);
         }
         issue_piece = issue_piece + 1 == n_pieces ? 0 : issue_piece + 1;
-        issue_slot = issue_slot + 1 == RING_PIECES ? 0 : issue_slot + 1;
+        issue_slot = wrap(issue_slot + 1);
+    }
+    // slot index modulo the ring (a mask when the ring has a power-of-two number of pieces)
+    static __device__ __forceinline__ uint32_t wrap(uint32_t slot) {
+        if constexpr ((RING_PIECES & (RING_PIECES - 1)) == 0) return slot & (RING_PIECES - 1);
+        else return slot >= RING_PIECES ? slot - RING_PIECES : slot;
     }
     __device__ __forceinline__ void init(const char* s, lds_bytes_t l, uint32_t np, int w, int ln) {
         src = s;
@@ -189,11 +194,10 @@ struct WeightRing {
         for (int i = 0; i < N; ++i) issue();
     }
     template <int N>
-    __device__ __forceinline__ void release() { piece = piece + N >= RING_PIECES ? piece + N - RING_PIECES : piece + N; }
+    __device__ __forceinline__ void release() { piece = wrap(piece + N); }
     // Address of unit `rel` (compile-time) of the segment that starts at `piece`.
     __device__ __forceinline__ lds_bytes_t unit_ptr(int rel) const {
-        uint32_t slot = piece + rel / PIECE_UNITS;
-        slot = slot >= RING_PIECES ? slot - RING_PIECES : slot;
+        const uint32_t slot = wrap(piece + rel / PIECE_UNITS);
         return lds + slot * (PIECE_UNITS * UNIT_BYTES) + (rel % PIECE_UNITS) * UNIT_BYTES + lane * 16;
     }
 };
