@@ -102,9 +102,7 @@ struct Tape {
     __device__ __forceinline__ void store_tile(int tile, int h, const f32x16& v) const {
         T* p = at(tile, 16 * h);
         if constexpr (BF16) {
-            using P = uint32_t (*)(float, float);
             auto pk = [](float lo, float hi) { uint32_t r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; };
-            (void)sizeof(P);
             reinterpret_cast<u32x4*>(p)[0] = u32x4{pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7])};
             reinterpret_cast<u32x4*>(p)[1] = u32x4{pk(v[8], v[9]), pk(v[10], v[11]), pk(v[12], v[13]), pk(v[14], v[15])};
         } else {
