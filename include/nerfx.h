@@ -207,6 +207,31 @@ int nerfx_render_fwd(const nerfx_model_t* coarse, const nerfx_model_t* fine, int
                      void* workspace, int64_t workspace_bytes,
                      float* t, float* weights, float* depth_map, float* rgb_map, void* stream);
 
+/* ---- camera rays in, display frames out (the callers either side of the path) ----------
+ * Turn-around camera poses: turnaround_poses (data/path.py:104-128) with turnaround
+ * (path.py:78-100) for each of `samples` steps of linspace(x0, x1, samples + 1)[:-1];
+ * poses (samples, 4, 4) camera-to-world. */
+int nerfx_orbit_poses(float theta0, float theta1, float phi0, float phi1, float psy0, float psy1,
+                      float radius0, float radius1, int samples, float* poses, void* stream);
+/* pinhole_ray_directions (ray.py:10-26): prd (H, W, 3), camera space, not normalised. */
+int nerfx_pinhole_directions(int H, int W, float focal, float* prd, void* stream);
+/* phinhole_ray_projection (ray.py:30-46): prd (n, 3), c2w (4, 4) -> ro, rd (n, 3), rd unit. */
+int nerfx_project_rays(const float* prd, int64_t n_rays, const float* c2w, float* ro, float* rd,
+                       void* stream);
+/* Both of the above for pixels [pixel_begin, pixel_begin + n_pixels) (row-major) of one pose,
+ * without the directions or the per-frame ray arrays of infer.py:114-121 in memory. */
+int nerfx_camera_rays(const float* c2w, int H, int W, float focal, int64_t pixel_begin,
+                      int64_t n_pixels, float* ro, float* rd, void* stream);
+/* Frame epilogue of infer (infer.py:58-66) and of its CLI (infer.py:145-146): depth (n) is
+ * NaN-cleaned, shifted by its minimum, divided by (maximum + 1e-10), clipped and scaled to
+ * [0, 255] on three channels; rgb (n, 3) is clipped and scaled.  Outputs (each may be NULL):
+ * float frames (n, 3) and 8-bit frames (n, 3) truncated like numpy's astype(uint8).
+ * `workspace`: nerfx_frame_workspace_bytes() bytes. */
+int64_t nerfx_frame_workspace_bytes(void);
+int nerfx_frame_finish(const float* depth, const float* rgb, int64_t n_pixels,
+                       void* workspace, int64_t workspace_bytes,
+                       float* depth_f32, float* rgb_f32, uint8_t* depth_u8, uint8_t* rgb_u8, void* stream);
+
 /* ---- diagnostics --------------------------------------------------------------------
  * No counterpart in the reference.  In a library built with -DNERFX_STAMPS the MLP kernels
  * add per-phase cycle counts (6 x uint64: prologue, ring hand-over, MFMA runs, epilogue,

@@ -16,7 +16,7 @@ def install_as(name: str = "nerf") -> None:
     """Alias this package (and its submodules) under another top-level name, so
     that code written as `from nerf.core import ...` picks up the HIP path."""
     from . import core, data, infer, train, utils  # noqa: F401
-    from .data import utils as _data_utils  # noqa: F401
+    from .data import path as _data_path, utils as _data_utils  # noqa: F401
     prefix = __name__ + "."
     for mod_name, mod in list(_sys.modules.items()):
         if mod_name == __name__ or mod_name.startswith(prefix):

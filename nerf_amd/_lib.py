@@ -52,6 +52,12 @@ SIGNATURES = {
     "nerfx_segment_lengths": (_i, [_p, _p, _l, _i, _p, _p]),
     "nerfx_pdf_sample": (_i, [_p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p]),
     "nerfx_searchsorted_right": (_i, [_p, _p, _l, _i, _i, _p, _p]),
+    "nerfx_orbit_poses": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _p, _p]),
+    "nerfx_pinhole_directions": (_i, [_i, _i, _f, _p, _p]),
+    "nerfx_project_rays": (_i, [_p, _l, _p, _p, _p, _p]),
+    "nerfx_camera_rays": (_i, [_p, _i, _i, _f, _l, _l, _p, _p, _p]),
+    "nerfx_frame_workspace_bytes": (_l, []),
+    "nerfx_frame_finish": (_i, [_p, _p, _l, _p, _l, _p, _p, _p, _p, _p]),
     "nerfx_debug_set_stamps": (None, [_p]),
     "nerfx_render_workspace_bytes": (_l, [_l, _i, _i]),
     "nerfx_render_fwd": (_i, [_p, _p, _i, _p, _p, _l, _f, _f, _i, _i, _p, _p, _p, _l,

@@ -1,12 +1,23 @@
-"""Ray sampling (the hot-path half of the reference's nerf/core/ray.py), backed by
-the HIP sampling kernels.  Camera-ray generation (`pinhole_ray_directions`,
-`phinhole_ray_projection`) is not part of this path."""
+"""Camera rays and ray sampling (the reference's nerf/core/ray.py), backed by the HIP kernels."""
 from typing import Tuple
 
 import torch
 from torch import Tensor
 
 from .. import ops
+
+
+def pinhole_ray_directions(H: int, W: int, focal: float, device=None) -> Tensor:
+    """Camera-space directions through the pixel grid, (1, H, W, 3) like the reference returns
+    (ray.py:10-26): ((i - W/2)/f, -(j - H/2)/f, -1) for column i, row j.  Lives on `device`
+    (default: the current ROCm device)."""
+    return ops.pinhole_directions(H, W, focal, device)[None]
+
+
+def phinhole_ray_projection(prd: Tensor, c2w: Tensor) -> Tuple[Tensor, Tensor]:
+    """Camera-space directions -> world-space origins and unit directions of the same shape
+    (reference ray.py:30-46)."""
+    return ops.project_rays(prd, c2w)
 
 
 def segment_lengths(t: Tensor, rd: Tensor) -> Tensor:

@@ -442,3 +442,69 @@ def render_train(coarse, fine, ro, rd, tn, tf, nc, nf, u_c, u_f):
             sigma, rgb = mlp_rays(handle_for(fine), ro, rd, t)
             w, rgb_map, depth = composite_fwd(sigma, rgb, t, rd)
     return t, w, depth, rgb_map
+
+
+# ---- camera rays in, display frames out ---------------------------------------------
+def _device(device) -> torch.device:
+    d = torch.device("cuda" if device is None else device)
+    if d.type != "cuda":
+        raise RuntimeError(f"nerf_amd runs on ROCm devices only: asked for {d}")
+    return torch.device("cuda", torch.cuda.current_device()) if d.index is None else d
+
+
+def orbit_poses(theta, phi, psy, radius, samples: int, device=None) -> Tensor:
+    """(samples, 4, 4) camera-to-world turn-around poses; each range is a (start, end) pair."""
+    dev = _device(device)
+    poses = torch.empty((samples, 4, 4), device=dev)
+    with torch.cuda.device(dev):
+        check(lib.nerfx_orbit_poses(theta[0], theta[1], phi[0], phi[1], psy[0], psy[1], radius[0], radius[1],
+                                    samples, _p(poses), _stream()))
+    return poses
+
+
+def pinhole_directions(H: int, W: int, focal: float, device=None) -> Tensor:
+    dev = _device(device)
+    prd = torch.empty((H, W, 3), device=dev)
+    with torch.cuda.device(dev):
+        check(lib.nerfx_pinhole_directions(H, W, focal, _p(prd), _stream()))
+    return prd
+
+
+def project_rays(prd: Tensor, c2w: Tensor) -> Tuple[Tensor, Tensor]:
+    prd, c2w = _dev(prd, "prd"), _dev(c2w, "c2w")
+    assert prd.shape[-1] == 3 and c2w.shape == (4, 4), "prd (..., 3) and c2w (4, 4)"
+    ro, rd = torch.empty_like(prd), torch.empty_like(prd)
+    with torch.cuda.device(prd.device):
+        check(lib.nerfx_project_rays(_p(prd), prd.numel() // 3, _p(c2w), _p(ro), _p(rd), _stream()))
+    return ro, rd
+
+
+def camera_rays(c2w: Tensor, H: int, W: int, focal: float, begin: int = 0,
+                count: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    """World-space rays of pixels [begin, begin + count) of an H x W pinhole frame seen from `c2w`."""
+    c2w = _dev(c2w, "c2w")
+    assert c2w.shape == (4, 4), "c2w (4, 4)"
+    count = H * W - begin if count is None else count
+    ro = torch.empty((count, 3), device=c2w.device)
+    rd = torch.empty((count, 3), device=c2w.device)
+    with torch.cuda.device(c2w.device):
+        check(lib.nerfx_camera_rays(_p(c2w), H, W, focal, begin, count, _p(ro), _p(rd), _stream()))
+    return ro, rd
+
+
+def frame_finish(depth: Tensor, rgb: Tensor, as_float: bool = True, as_uint8: bool = False):
+    """Per-pixel depth (n) and rgb (n, 3) -> display frames (n, 3) in [0, 255]:
+    (depth_f32, rgb_f32, depth_u8, rgb_u8), None where not asked for."""
+    depth, rgb = _dev(depth, "depth").reshape(-1), _dev(rgb, "rgb").reshape(-1, 3)
+    n = depth.numel()
+    assert rgb.shape[0] == n, "depth and rgb disagree on the pixel count"
+    dev = depth.device
+    ws = torch.empty((lib.nerfx_frame_workspace_bytes(),), dtype=torch.uint8, device=dev)
+    df = torch.empty((n, 3), device=dev) if as_float else None
+    cf = torch.empty((n, 3), device=dev) if as_float else None
+    du = torch.empty((n, 3), dtype=torch.uint8, device=dev) if as_uint8 else None
+    cu = torch.empty((n, 3), dtype=torch.uint8, device=dev) if as_uint8 else None
+    with torch.cuda.device(dev):
+        check(lib.nerfx_frame_finish(_p(depth), _p(rgb), n, _p(ws), ws.numel(), _p(df), _p(cf), _p(du), _p(cu),
+                                     _stream()))
+    return df, cf, du, cu

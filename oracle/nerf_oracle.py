@@ -282,6 +282,48 @@ def infer(coarse: Model, fine: Model, ro, rd, H, W, tn, tf, n_coarse, n_fine, ba
     return postprocess_frame(depth, rgb, H, W)
 
 
+# ---- camera rays and poses (callers of the path) ---------------------------------------
+def pinhole_ray_directions(H: int, W: int, focal: float) -> Tensor:
+    """ray.py:10-26 -> (1, H, W, 3).  The pixel grid comes from kornia's create_meshgrid
+    (0.5.11, not vendored by the reference: parity unpinned for that one call): x = column
+    index 0..W-1, y = row index 0..H-1, un-normalised."""
+    j, i = torch.meshgrid(torch.linspace(0, H - 1, H), torch.linspace(0, W - 1, W), indexing="ij")
+    i, j = i[None], j[None]
+    rdx = (i - .5 * W) / focal
+    rdy = (j - .5 * H) / focal
+    rdz = torch.ones_like(i)
+    return torch.stack((rdx, -rdy, -rdz), dim=-1)
+
+
+def pinhole_ray_projection(prd: Tensor, c2w: Tensor) -> Tuple[Tensor, Tensor]:
+    """ray.py:30-46 (`phinhole_ray_projection`): rotate, normalise, broadcast the origin."""
+    rd = prd @ c2w[:3, :3].T
+    rd = rd / torch.norm(rd, dim=-1, keepdim=True)
+    return c2w[:3, 3].expand(rd.size()), rd
+
+
+def turnaround(theta: Tensor, phi: Tensor, psy: Tensor, radius: Tensor) -> Tensor:
+    """path.py:9-100: diag(-1,1,1,1) @ R_theta @ R_phi @ R_psy @ T_z, fp32."""
+    c, s = torch.cos, torch.sin
+    t = torch.tensor([[c(theta), 0., s(theta), 0.], [0., 1., 0., 0.], [-s(theta), 0., c(theta), 0.], [0., 0., 0., 1.]])
+    p = torch.tensor([[1., 0., 0., 0.], [0., c(phi), -s(phi), 0.], [0., s(phi), c(phi), 0.], [0., 0., 0., 1.]])
+    y = torch.tensor([[c(psy), -s(psy), 0., 0.], [s(psy), c(psy), 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]])
+    z = torch.tensor([[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., radius], [0., 0., 0., 1.]])
+    flip = torch.tensor([[-1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]])
+    return flip @ t @ p @ y @ z
+
+
+def turnaround_poses(theta, phi, psy, radius, samples: int) -> Tensor:
+    """path.py:104-128 -> (samples, 4, 4)."""
+    cols = [torch.linspace(lo, hi, samples + 1)[:-1] for lo, hi in (theta, phi, psy, radius)]
+    return torch.stack([turnaround(*tpyr) for tpyr in zip(*cols)], dim=0)
+
+
+def frame_to_uint8(frame: Tensor):
+    """infer.py:145-146: `frame.numpy().astype(np.uint8)` (truncation)."""
+    return frame.numpy().astype("uint8")
+
+
 def train_step(params: Params, enc_x, enc_d, activ, resid, ro, rd, target, tn, tf,
                n_coarse, n_fine, u_coarse, u_fine, optim: torch.optim.Optimizer):
     """train.py:75-86 with the GradScaler disabled: one render(train=True) + MSE

@@ -153,3 +153,32 @@ def test_g8_infer():
                      meta["nc"], meta["nf"], batch_size=100)
     assert_close(dn, g["nan_depth"], rtol=1e-5, atol=1e-3, what="nan depth")
     assert_close(cn, g["nan_rgb"], rtol=1e-5, atol=1e-3, what="nan rgb")
+
+
+def test_g10_camera_rays_and_poses():
+    """Camera rays and turn-around poses as the reference's CLI builds them (infer.py:110-121).
+    The pixel-grid convention inside pinhole_ray_directions comes from kornia (absent): that
+    one call is parity unpinned, everything downstream of it is the reference's own code."""
+    import numpy as np
+    meta, g = load_golden("g10_camera")
+    ranges = (-np.pi, np.pi), (-np.pi, np.pi), (-np.pi, np.pi), (4., 4.)
+    poses = O.turnaround_poses(*ranges, 8)
+    assert_close(poses, g["poses8"], rtol=0, atol=1e-6, what="poses8")
+    alt = O.turnaround_poses((0.25, 1.5), (-0.5, 0.75), (0., 0.), (3., 5.), 5)
+    assert_close(alt, g["poses5_alt"], rtol=0, atol=1e-6, what="poses5_alt")
+    for H, W in meta["sizes"]:
+        focal = .5 * W / np.tan(.5 * meta["cam_angle_x"])
+        prd = O.pinhole_ray_directions(H, W, focal)
+        assert prd.shape == (1, H, W, 3)
+        assert torch.equal(prd, g[f"prd_{H}x{W}"])
+        for k in meta["pose_ids"]:
+            ro, rd = O.pinhole_ray_projection(prd, g["poses8"][k])
+            assert torch.equal(ro, g[f"ro_{H}x{W}_{k}"]) and torch.equal(rd, g[f"rd_{H}x{W}_{k}"])
+            assert_close(rd.norm(dim=-1), torch.ones(1, H, W), rtol=1e-6, atol=0, what="unit directions")
+
+
+def test_frame_to_uint8_truncates():
+    _, g = load_golden("g8_infer")
+    u8 = O.frame_to_uint8(g["depth"])
+    assert u8.dtype.name == "uint8" and u8.max() <= 255
+    assert (u8 == g["depth"].floor().to(torch.uint8).numpy()).all()

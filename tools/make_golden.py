@@ -289,9 +289,47 @@ def g9_schedulers():
     save("g9_schedulers", {}, **out)
 
 
+def _load_reference_path_module():
+    """nerf/data/path.py by file: `import nerf.data` pulls in torchvision (absent)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_data_path", "/root/reference/nerf/data/path.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_data_path"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@torch.no_grad()
+def g10_camera():
+    """Camera rays as the reference's CLI builds them (infer.py:110-121).  The pixel grid inside
+    pinhole_ray_directions comes from the kornia stand-in: that one convention is unpinned."""
+    ref_path = _load_reference_path_module()
+    out = {}
+    cam_angle_x = 0.6194058656692505                               # infer.py:85
+    ranges = (-np.pi, np.pi), (-np.pi, np.pi), (-np.pi, np.pi), (4., 4.)
+    poses = ref_path.turnaround_poses(*ranges, 8)
+    out["poses8"] = poses
+    out["poses5_alt"] = ref_path.turnaround_poses((0.25, 1.5), (-0.5, 0.75), (0., 0.), (3., 5.), 5)
+    sizes = ((6, 10), (9, 7), (16, 16))
+    for H, W in sizes:
+        focal = .5 * W / np.tan(.5 * cam_angle_x)
+        prd = ref_ray.pinhole_ray_directions(H, W, focal)
+        out[f"prd_{H}x{W}"] = prd
+        for k in (0, 3, 5):
+            ro, rd = ref_ray.phinhole_ray_projection(prd, poses[k])
+            out[f"ro_{H}x{W}_{k}"] = ro.contiguous()
+            out[f"rd_{H}x{W}_{k}"] = rd
+    save("g10_camera", dict(cam_angle_x=cam_angle_x, sizes=[list(s) for s in sizes], pose_ids=[0, 3, 5]), **out)
+
+
+ALL = (g1_sampling, g2_encodings, g3_mlp, g4_composite, g5_pdf, g6_render, g7_train, g8_infer,
+       g9_schedulers, g10_camera)
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for fn in (g1_sampling, g2_encodings, g3_mlp, g4_composite, g5_pdf, g6_render, g7_train,
-               g8_infer, g9_schedulers):
+    wanted = sys.argv[1:]                      # e.g. `python tools/make_golden.py g10_camera`
+    for fn in ALL:
+        if wanted and fn.__name__ not in wanted:
+            continue
         print(fn.__name__)
         fn()
