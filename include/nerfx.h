@@ -232,6 +232,28 @@ int nerfx_frame_finish(const float* depth, const float* rgb, int64_t n_pixels,
                        void* workspace, int64_t workspace_bytes,
                        float* depth_f32, float* rgb_f32, uint8_t* depth_u8, uint8_t* rgb_u8, void* stream);
 
+/* ---- around the render in a training step (the caller `step`, train.py:72-99) -------------
+ * A batch of rays out of device-resident arrays: item k = (C, ro, rd)[perm[begin + k]]
+ * (perm == NULL: item begin + k), what the reference's DataLoader collates from
+ * BlenderDataset.__getitem__ (blender.py:224-235; data/utils.py:26-32).  Arrays are (n_total, 3). */
+int nerfx_gather_rays(const float* C, const float* ro, const float* rd, const int64_t* perm,
+                      int64_t begin, int64_t n, int64_t n_total,
+                      float* C_out, float* ro_out, float* rd_out, void* stream);
+/* MSELoss(reduction="mean") (train.py:77, :278) and PSNR = -10 log10(loss) (train.py:92):
+ * loss_psnr[0], loss_psnr[1]; grad_seed (n_elements, may be NULL) = d loss / d pred.
+ * One fixed summation order: bit-reproducible. */
+int nerfx_mse_loss(const float* pred, const float* target, int64_t n_elements, float* loss_psnr,
+                   float* grad_seed, void* stream);
+/* torch.optim.Adam's update (train.py:246) over flat fp32 arrays of n elements, with the
+ * GradScaler's part of train.py:82-85 folded in: gradients are multiplied by *inv_scale when
+ * given, and nothing is updated when *found_inf != 0 (device floats, may be NULL).  The update
+ * count lives on the device: *step_in updates have been applied, *step_out receives the new
+ * count (two distinct floats; swap them between calls). */
+int nerfx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay,
+                    const float* inv_scale, const float* found_inf,
+                    const float* step_in, float* step_out, void* stream);
+
 /* ---- diagnostics --------------------------------------------------------------------
  * No counterpart in the reference.  In a library built with -DNERFX_STAMPS the MLP kernels
  * add per-phase cycle counts (6 x uint64: prologue, ring hand-over, MFMA runs, epilogue,

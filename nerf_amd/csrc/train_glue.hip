@@ -1,0 +1,124 @@
+// What surrounds the render in one optimisation step (train.py:72-99): the batch gather, the
+// MSE loss with its PSNR and gradient seed, and the Adam update with the loss scaler's inf check.
+// Small, bandwidth-bound kernels whose point is that nothing in a step waits for the host.
+#include "common.hpp"
+
+namespace nerfx {
+
+// ---- batch gather (data/utils.py:26-32 + blender.py:224-235: one item = colour, origin, direction)
+__global__ __launch_bounds__(256) void gather_rays_kernel(const float* __restrict__ C, const float* __restrict__ ro,
+                                                          const float* __restrict__ rd, const int64_t* __restrict__ perm,
+                                                          int64_t begin, int64_t n, int64_t n_total,
+                                                          float* __restrict__ C_out, float* __restrict__ ro_out,
+                                                          float* __restrict__ rd_out) {
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (int64_t)gridDim.x * 256) {
+        int64_t src = perm ? perm[begin + q] : begin + q;
+        src = src < 0 ? 0 : (src >= n_total ? n_total - 1 : src);           // a bad index must not fault
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            C_out[3 * q + c] = C[3 * src + c];
+            ro_out[3 * q + c] = ro[3 * src + c];
+            rd_out[3 * q + c] = rd[3 * src + c];
+        }
+    }
+}
+
+// ---- MSE + PSNR + gradient seed (train.py:77, :92) ------------------------------------------
+// One workgroup: a fixed summation order, so the loss is bit-reproducible from run to run.
+constexpr int MSE_THREADS = 1024;
+__global__ __launch_bounds__(MSE_THREADS) void mse_loss_kernel(const float* __restrict__ pred,
+                                                               const float* __restrict__ target, int64_t n,
+                                                               float* __restrict__ out2, float* __restrict__ seed) {
+    __shared__ float part[MSE_THREADS / 64];
+    const float inv_n = 1.0f / (float)n, two_inv_n = 2.0f / (float)n;
+    float acc = 0.f;
+    for (int64_t q = threadIdx.x; q < n; q += MSE_THREADS) {
+        const float d = pred[q] - target[q];
+        acc = fmaf(d, d, acc);
+        if (seed) seed[q] = d * two_inv_n;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < MSE_THREADS / 64; ++w) s += part[w];
+        const float loss = s * inv_n;
+        out2[0] = loss;
+        out2[1] = -10.0f * log10f(loss);
+    }
+}
+
+// ---- Adam (torch.optim.Adam, train.py:246) with the GradScaler's checks folded in -----------
+// step_io[0] is the number of updates applied so far; the kernel applies update number
+// step_io[0] + 1 and writes that count to step_io[1] (the caller swaps the two between calls),
+// unless *found_inf is non-zero: then nothing changes, as when GradScaler.step skips optim.step.
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                        float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                                                        int64_t n, float lr, float beta1, float beta2, float eps,
+                                                        float weight_decay, const float* __restrict__ inv_scale,
+                                                        const float* __restrict__ found_inf,
+                                                        const float* __restrict__ step_in, float* __restrict__ step_out) {
+    const bool skip = found_inf && *found_inf != 0.f;
+    const float step = *step_in + (skip ? 0.f : 1.f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *step_out = step;
+    if (skip) return;
+    // bias corrections in double like the Python scalars of torch.optim.Adam
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const float unscale = inv_scale ? *inv_scale : 1.0f;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (int64_t)gridDim.x * 256) {
+        float g = grad[q] * unscale;
+        const float p = param[q];
+        if (weight_decay != 0.f) g = fmaf(weight_decay, p, g);
+        const float m = fmaf(1.0f - beta1, g - exp_avg[q], exp_avg[q]);          // lerp_(grad, 1 - beta1)
+        const float v = fmaf(1.0f - beta2, g * g, exp_avg_sq[q] * beta2);        // mul_(beta2).addcmul_(g, g, 1 - beta2)
+        exp_avg[q] = m;
+        exp_avg_sq[q] = v;
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        param[q] = fmaf(-step_size, m / denom, p);                               // addcdiv_(m, denom, -step_size)
+    }
+}
+
+}  // namespace nerfx
+
+using namespace nerfx;
+
+extern "C" int nerfx_gather_rays(const float* C, const float* ro, const float* rd, const int64_t* perm,
+                                 int64_t begin, int64_t n, int64_t n_total, float* C_out, float* ro_out,
+                                 float* rd_out, void* stream) {
+    NERFX_REQUIRE(n >= 0 && begin >= 0 && n_total >= 0, "negative size");
+    if (n == 0) return 0;
+    NERFX_REQUIRE(n_total > 0 && (perm || begin + n <= n_total), "rays [%lld, +%lld) outside the %lld stored",
+                  (long long)begin, (long long)n, (long long)n_total);
+    NERFX_REQUIRE(C && ro && rd && C_out && ro_out && rd_out, "a ray array is NULL");
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(gather_rays_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, ro, rd, perm, begin, n,
+                       n_total, C_out, ro_out, rd_out);
+    return launch_status("gather_rays_kernel");
+}
+
+extern "C" int nerfx_mse_loss(const float* pred, const float* target, int64_t n_elements, float* loss_psnr,
+                              float* grad_seed, void* stream) {
+    NERFX_REQUIRE(n_elements > 0, "n_elements <= 0");
+    NERFX_REQUIRE(pred && target && loss_psnr, "pred / target / loss_psnr is NULL");
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(MSE_THREADS), 0, (hipStream_t)stream, pred, target, n_elements,
+                       loss_psnr, grad_seed);
+    return launch_status("mse_loss_kernel");
+}
+
+extern "C" int nerfx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               float lr, float beta1, float beta2, float eps, float weight_decay,
+                               const float* inv_scale, const float* found_inf, const float* step_in,
+                               float* step_out, void* stream) {
+    NERFX_REQUIRE(n >= 0, "n < 0");
+    NERFX_REQUIRE(step_in && step_out && step_in != step_out, "step_in / step_out must be two device floats");
+    NERFX_REQUIRE(n == 0 || (param && grad && exp_avg && exp_avg_sq), "param / grad / exp_avg / exp_avg_sq is NULL");
+    NERFX_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "betas outside [0, 1)");
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 8));
+    hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, inv_scale, found_inf, step_in, step_out);
+    return launch_status("adam_step_kernel");
+}

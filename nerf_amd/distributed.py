@@ -97,6 +97,24 @@ def infer_sharded(coarse, fine, raymarcher, ro: Tensor, rd: Tensor, H: int, W: i
     return postprocess(frame[:, 3], frame[:, :3], H, W)
 
 
+def flat_gradient(params) -> Optional[Tensor]:
+    """The gradients of `params` as ONE flat tensor if they already are consecutive views of one
+    buffer in this order (as the MLP backward above returns them), else None.  No copy."""
+    grads = [p.grad for p in params]
+    if not grads or any(g is None or g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
+        return None
+    base, ptr = grads[0], grads[0].data_ptr()
+    for g in grads:
+        if g.data_ptr() != ptr or g.device != base.device:
+            return None
+        ptr += 4 * g.numel()
+    total = (ptr - base.data_ptr()) // 4
+    storage = base.untyped_storage()
+    if base.storage_offset() + total > storage.nbytes() // 4:
+        return None
+    return torch.empty(0, dtype=torch.float32, device=base.device).set_(storage, base.storage_offset(), (total,), (1,))
+
+
 class GradientBucket:
     """All gradients of a parameter list as one flat fp32 buffer and one all-reduce."""
 
@@ -113,6 +131,11 @@ class GradientBucket:
         only if some rank has one; the set of trained parameters must agree across ranks."""
         rank, ws = world(group)
         if ws == 1:
+            return
+        flat = flat_gradient(self.params)        # the MLP backward's own flat buffer: no staging copies
+        if flat is not None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            flat.mul_(1.0 / ws)
             return
         have = [p.grad is not None for p in self.params]
         self.flat.zero_()

@@ -374,7 +374,12 @@ class _FieldFunction(torch.autograd.Function):
         dev = sigma.device
         g_sigma = torch.zeros_like(sigma) if g_sigma is None else _dev(g_sigma, "g_sigma")
         g_rgb = torch.zeros_like(rgb) if g_rgb is None else _dev(g_rgb, "g_rgb")
-        grads = [torch.empty(shape, device=dev) if need else None for shape, need in ctx.param_meta]
+        # one flat buffer, one view per parameter in module.parameters() order: the optimizer and the
+        # data-parallel all-reduce can then work on the whole gradient at once (distributed.flat_gradient)
+        sizes = [int(torch.Size(shape).numel()) if need else 0 for shape, need in ctx.param_meta]
+        flat = torch.empty((sum(sizes),), device=dev)
+        grads = [v.view(shape) if need else None
+                 for v, (shape, need) in zip(flat.split(sizes), ctx.param_meta)]
         slots = [None, None] + grads                                 # the two encoder tables come first
         arr = (C.c_void_p * len(slots))(*[None if g is None else g.data_ptr() for g in slots])
         if ctx.M > 0:
@@ -508,3 +513,58 @@ def frame_finish(depth: Tensor, rgb: Tensor, as_float: bool = True, as_uint8: bo
         check(lib.nerfx_frame_finish(_p(depth), _p(rgb), n, _p(ws), ws.numel(), _p(df), _p(cf), _p(du), _p(cu),
                                      _stream()))
     return df, cf, du, cu
+
+
+# ---- around the render in a training step -------------------------------------------------
+def gather_rays(C: Tensor, ro: Tensor, rd: Tensor, perm: Optional[Tensor], begin: int, n: int):
+    C, ro, rd = _dev(C, "C"), _dev(ro, "ro"), _dev(rd, "rd")
+    assert C.shape == ro.shape == rd.shape and C.shape[-1] == 3, "C, ro, rd must all be (N, 3)"
+    perm = None if perm is None else _dev(perm, "perm", torch.int64)
+    out = [torch.empty((n, 3), device=C.device) for _ in range(3)]
+    with torch.cuda.device(C.device):
+        check(lib.nerfx_gather_rays(_p(C), _p(ro), _p(rd), _p(perm), begin, n, C.shape[0],
+                                    _p(out[0]), _p(out[1]), _p(out[2]), _stream()))
+    return out
+
+
+class _MSEFunction(torch.autograd.Function):
+    """mean((pred - target)^2) with the PSNR on the side and d loss / d pred formed in the same pass."""
+
+    @staticmethod
+    def forward(ctx, pred, target, loss_psnr):
+        seed = torch.empty_like(pred)
+        with torch.cuda.device(pred.device):
+            check(lib.nerfx_mse_loss(_p(pred), _p(target), pred.numel(), _p(loss_psnr), _p(seed), _stream()))
+        ctx.save_for_backward(seed)
+        return loss_psnr[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (seed,) = ctx.saved_tensors
+        return seed * g, None, None
+
+
+def mse_loss(pred: Tensor, target: Tensor, loss_psnr: Optional[Tensor] = None) -> Tensor:
+    """MSELoss (mean) as a 0-dim tensor; `loss_psnr` (2 floats on the device, optional) receives
+    the loss and -10 log10(loss)."""
+    pred, target = _dev(pred, "pred"), _dev(target.detach(), "target")
+    assert pred.shape == target.shape, "pred and target shapes differ"
+    if loss_psnr is None:
+        loss_psnr = torch.empty((2,), device=pred.device)
+    if pred.requires_grad and torch.is_grad_enabled():
+        return _MSEFunction.apply(pred, target, loss_psnr)
+    with torch.cuda.device(pred.device):
+        check(lib.nerfx_mse_loss(_p(pred), _p(target), pred.numel(), _p(loss_psnr), None, _stream()))
+    return loss_psnr[0]
+
+
+def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float,
+              beta2: float, eps: float, weight_decay: float, inv_scale: Optional[Tensor],
+              found_inf: Optional[Tensor], step_in: Tensor, step_out: Tensor) -> None:
+    n = param.numel()
+    for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+            raise RuntimeError(f"adam_step: `{name}` must be a contiguous fp32 ROCm tensor of {n} elements")
+    with torch.cuda.device(param.device):
+        check(lib.nerfx_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lr, beta1, beta2, eps,
+                                  weight_decay, _p(inv_scale), _p(found_inf), _p(step_in), _p(step_out), _stream()))

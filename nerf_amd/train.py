@@ -7,7 +7,12 @@ operations of one optimisation step (train.py:75-86):
     -> scaler.update -> optim.zero_grad(set_to_none=True) -> scheduler.step
 The render and its backward run on the HIP kernels; `autocast` selects the bf16 MFMA
 contractions (the loss scale of a GradScaler then only rescales fp32 gradients, which
-is harmless).  Optimizer, scaler, criterion and scheduler are the caller's objects.
+is harmless).  Optimizer, scaler, criterion and scheduler are the caller's objects; a plain
+`MSELoss()` is computed by the fused loss kernel (loss, PSNR and gradient seed in one pass).
+Losses and PSNRs are kept on the device and fetched every `LOG_EVERY` steps (and at the end of
+the pass), not with four `.item()` calls per step as the reference does (train.py:94-97): the
+returned lists are the same, the progress bar refreshes less often, and with
+`nerf_amd.optim.Adam` no step waits for the host.
 When torch.distributed is initialised with more than one rank, every rank runs this loop on
 its own batches and the gradients are averaged (one flat all-reduce) before `unscale_`.
 """
@@ -21,6 +26,7 @@ from torch.nn.utils import clip_grad_norm_
 from torch.optim import Optimizer
 from torch.utils.data import DataLoader, Dataset
 
+from . import ops
 from .core.model import NeRF
 from .core.renderer import BoundedVolumeRaymarcher as BVR
 from .core.scheduler import Scheduler
@@ -30,6 +36,7 @@ from .utils.history import History
 from .utils.pbar import tqdm
 
 GRAD_NORM_CLIP = 0.
+LOG_EVERY = 32          # steps between fetches of the device-side loss / PSNR log
 
 
 def step(epoch: int, nerf: NeRF, raymarcher: BVR, optim: Optimizer, scheduler: Scheduler, criterion: Module,
@@ -42,14 +49,32 @@ def step(epoch: int, nerf: NeRF, raymarcher: BVR, optim: Optimizer, scheduler: S
     total_loss, total_psnr, total_lr = 0., 0., 0.
     steps_loss, steps_psnr, steps_lr = [], [], []
     batches = tqdm(loader, desc=f"[NeRF] {split.capitalize()} {epoch + 1}", disable=not verbose)
+    fused_mse = type(criterion) is torch.nn.MSELoss and criterion.reduction == "mean"
+    log = torch.zeros((len(loader), 2), dtype=torch.float32, device=d)      # loss, psnr per step
+    fetched = 0
+
+    def fetch(upto: int) -> None:
+        nonlocal fetched, total_loss, total_psnr
+        if upto <= fetched:
+            return
+        for loss_k, psnr_k in log[fetched:upto].tolist():
+            total_loss += loss_k / len(loader)
+            total_psnr += psnr_k / len(loader)
+            steps_loss.append(loss_k)
+            steps_psnr.append(psnr_k)
+        fetched = upto
+        batches.set_postfix(loss=total_loss, psnr=total_psnr, lr=total_lr)
 
     with torch.set_grad_enabled(train):
-        for C, ro, rd in batches:
+        for k, (C, ro, rd) in enumerate(batches):
             C, ro, rd = C.to(d), ro.to(d), rd.to(d)
 
             with torch.autocast("cuda", enabled=scaler.is_enabled()):
                 *_, C_ = raymarcher.render_volume(nerf, nerf, ro, rd, perturb=perturb, train=train)
-                loss = criterion(C_, C)
+                if fused_mse:
+                    loss = ops.mse_loss(C_, C, log[k])
+                else:
+                    loss = criterion(C_, C)
 
             if train:
                 scaler.scale(loss).backward()
@@ -65,14 +90,13 @@ def step(epoch: int, nerf: NeRF, raymarcher: BVR, optim: Optimizer, scheduler: S
                 total_lr += scheduler.lr / len(loader)
                 steps_lr.append(scheduler.lr)
 
-            with torch.no_grad():
-                psnr = -10. * torch.log10(loss)
-
-            total_loss += loss.item() / len(loader)
-            total_psnr += psnr.item() / len(loader)
-            steps_loss.append(loss.item())
-            steps_psnr.append(psnr.item())
-            batches.set_postfix(loss=total_loss, psnr=total_psnr, lr=total_lr)
+            if not fused_mse:
+                with torch.no_grad():
+                    log[k, 0] = loss.detach()
+                    log[k, 1] = -10. * torch.log10(loss.detach())
+            if (k + 1) % LOG_EVERY == 0:
+                fetch(k + 1)
+        fetch(len(loader))
 
     return steps_loss, steps_psnr, steps_lr
 
@@ -84,10 +108,10 @@ def fit(nerf: NeRF, raymarcher: BVR, optim: Optimizer, scheduler: Scheduler, cri
         verbose: bool = True) -> History:
     """Fit `nerf` on a ray dataset (reference train.py:104-177): per epoch a train pass, an
     optional validation pass and the callbacks; a test pass at the end."""
-    train, val, test = loaders(train_data, val_data, test_data, batch_size, jobs)
+    d = next(nerf.parameters()).device
+    train, val, test = loaders(train_data, val_data, test_data, batch_size, jobs, device=d)
 
     H = History()
-    d = next(nerf.parameters()).device
     args = nerf, raymarcher, optim, scheduler, criterion, scaler
 
     pbar = tqdm(range(epochs), desc="[NeRF] Epoch", disable=not verbose)

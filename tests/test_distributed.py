@@ -107,3 +107,22 @@ def test_single_process_is_a_no_op():
     assert D.world() == (0, 1)
     x = torch.arange(12.0).view(4, 3)
     assert torch.equal(D.gather_rays(x, 4), x)
+
+
+def test_flat_gradient_detection():
+    """Consecutive views of one buffer are recognised (and shared, not copied); anything else is not."""
+    from nerf_amd.distributed import flat_gradient
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in ((4, 3), (4,), (2, 4))]
+    sizes = [p.numel() for p in params]
+    flat = torch.arange(float(sum(sizes)))
+    for p, v in zip(params, flat.split(sizes)):
+        p.grad = v.view(p.shape)
+    got = flat_gradient(params)
+    assert got is not None and got.data_ptr() == flat.data_ptr() and torch.equal(got, flat)
+    got.mul_(2.0)
+    assert torch.equal(params[2].grad, (flat.split(sizes)[2]).view(2, 4))          # shared storage
+    params[1].grad = torch.zeros(4)                                                # a separate allocation
+    assert flat_gradient(params) is None
+    params[1].grad = None
+    assert flat_gradient(params) is None
+    assert flat_gradient([]) is None

@@ -1,0 +1,161 @@
+"""The kernels around the render in a training step (batch gather, fused MSE / PSNR / gradient
+seed, flat Adam with the loss scaler's inf check) against torch's own implementations, which
+are what the reference's step uses (train.py:72-99).  Through the C ABI.
+
+Tolerances: gather exact; loss and PSNR 1e-6 relative (a different summation order); Adam
+1e-6 absolute / 1e-5 relative per step against torch.optim.Adam on the same gradients.
+"""
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import assert_close, product_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ops():
+    import nerf_amd.ops as ops_
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    ops_.set_precision(None)
+    yield ops_
+    ops_.set_precision(None)
+
+
+def test_gather_rays(ops):
+    g = torch.Generator().manual_seed(3)
+    N = 1000
+    C, ro, rd = (torch.rand(N, 3, generator=g).cuda() for _ in range(3))
+    perm = torch.randperm(N, generator=g).cuda()
+    for begin, n in ((0, 256), (900, 100), (17, 1), (0, 0)):
+        a, b, c = ops.gather_rays(C, ro, rd, perm, begin, n)
+        idx = perm[begin:begin + n]
+        assert torch.equal(a, C[idx]) and torch.equal(b, ro[idx]) and torch.equal(c, rd[idx])
+        a, b, c = ops.gather_rays(C, ro, rd, None, begin, n)
+        assert torch.equal(a, C[begin:begin + n]) and torch.equal(c, rd[begin:begin + n])
+    with pytest.raises(RuntimeError):
+        ops.gather_rays(C, ro, rd, None, 990, 20)
+
+
+@pytest.mark.parametrize("n", [1, 5, 4096, 100_003])
+def test_mse_loss_psnr_and_gradient(ops, n):
+    g = torch.Generator().manual_seed(n)
+    pred = torch.rand(n, 3, generator=g).cuda().requires_grad_(True)
+    target = torch.rand(n, 3, generator=g).cuda()
+    log = torch.zeros(2, device="cuda")
+    loss = ops.mse_loss(pred, target, log)
+    (loss * 3.0).backward()
+    ref_pred = pred.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.mse_loss(ref_pred, target)
+    (ref * 3.0).backward()
+    assert_close(loss.detach().cpu(), ref.detach().cpu(), rtol=1e-6, atol=0, what="loss")
+    assert_close(log.cpu(), torch.stack((ref.detach(), -10 * torch.log10(ref.detach()))).cpu(), rtol=2e-6, atol=1e-6,
+                 what="loss / psnr log")
+    assert_close(pred.grad.cpu(), ref_pred.grad.cpu(), rtol=1e-6, atol=1e-12, what="gradient seed")
+    # no-grad form and run-to-run reproducibility
+    with torch.no_grad():
+        again = ops.mse_loss(pred, target)
+    assert torch.equal(again, loss.detach())
+
+
+def _param_sets(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(256, 39), (256,), (128, 295), (3, 128), (3,)]
+    a = [torch.nn.Parameter((torch.rand(s, generator=g) - 0.5).cuda()) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    return a, b, g
+
+
+@pytest.mark.parametrize("weight_decay", [0.0, 0.01])
+def test_flat_adam_matches_torch_adam(ops, weight_decay):
+    from nerf_amd.optim import Adam
+    mine, theirs, g = _param_sets(11)
+    opt_a = Adam(mine, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay)
+    opt_b = torch.optim.Adam(theirs, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay)
+    base = mine[0].data_ptr()
+    assert all(p.data_ptr() == base + 4 * sum(q.numel() for q in mine[:i]) for i, p in enumerate(mine)), "flat views"
+    for it in range(6):
+        for p, q in zip(mine, theirs):
+            grad = (torch.rand(p.shape, generator=g) - 0.5).cuda() * (10.0 ** (it - 3))
+            p.grad, q.grad = grad.clone(), grad.clone()
+        v0 = mine[0]._version
+        opt_a.step()
+        opt_b.step()
+        assert mine[0]._version > v0, "the update must be visible to version-based caches"
+        for k, (p, q) in enumerate(zip(mine, theirs)):
+            assert_close(p.detach().cpu(), q.detach().cpu(), rtol=1e-5, atol=1e-6, what=f"step {it} tensor {k}")
+    assert opt_a.steps_applied == 6
+
+
+def test_flat_adam_behind_grad_scaler_skips_on_inf(ops):
+    from nerf_amd.optim import Adam
+    mine, theirs, g = _param_sets(12)
+    opt_a, opt_b = Adam(mine, lr=1e-3), torch.optim.Adam(theirs, lr=1e-3)
+    sc_a = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    sc_b = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    for it in range(4):
+        for p, q in zip(mine, theirs):
+            grad = (torch.rand(p.shape, generator=g) - 0.5).cuda() * 1024.0      # "scaled" gradients
+            if it == 1:
+                grad.view(-1)[0] = float("inf")
+            p.grad, q.grad = grad.clone(), grad.clone()
+        for sc, opt in ((sc_a, opt_a), (sc_b, opt_b)):
+            sc._lazy_init_scale_growth_tracker(torch.device("cuda")) if sc._scale is None else None
+            if it % 2 == 0:
+                sc.unscale_(opt)                     # the reference's order (train.py:82); else let step() unscale
+            sc.step(opt)
+            sc.update()
+        for k, (p, q) in enumerate(zip(mine, theirs)):
+            assert_close(p.detach().cpu(), q.detach().cpu(), rtol=1e-5, atol=1e-6, what=f"step {it} tensor {k}")
+    assert opt_a.steps_applied == 3, "the step with an inf gradient must be skipped on the device"
+    assert sc_a.get_scale() == sc_b.get_scale() == 512.0
+
+
+def test_train_step_with_fused_glue_matches_torch_glue(ops):
+    """nerf_amd.train.step with (DeviceRayLoader, fused MSE, flat Adam) == the same step with
+    (DataLoader, torch Adam): same weights after an epoch of 3 steps, same returned lists."""
+    import nerf_amd.train as T
+    from nerf_amd.core import BoundedVolumeRaymarcher, IndendityScheduler
+    from nerf_amd.data.utils import DeviceRayLoader, loaders
+    from nerf_amd.distributed import flat_gradient
+    from nerf_amd.optim import Adam
+    meta, gold = load_golden("g7_train_student")
+    g = torch.Generator().manual_seed(21)
+
+    class Rays(torch.utils.data.Dataset):
+        def __init__(self):
+            self.C, self.ro, self.rd = (torch.rand(96, 3, generator=g) for _ in range(3))
+
+        def __len__(self):
+            return self.C.size(0)
+
+        def __getitem__(self, i):
+            return self.C[i], self.ro[i], self.rd[i]
+
+    data = Rays()
+    bvr = BoundedVolumeRaymarcher(2.0, 6.0, 16, 16)
+    ops.set_precision("fp32")
+    results = []
+    for fused in (True, False):
+        model = product_model(meta["model"], gold)
+        optim = (Adam if fused else torch.optim.Adam)(model.parameters(), lr=5e-4, eps=1e-8)
+        sched = IndendityScheduler(optim, 1, 5e-4)
+        scaler = torch.amp.GradScaler("cuda", enabled=False)
+        _, val, _ = loaders(None, data, None, 32, 0, device="cuda" if fused else None)    # unshuffled: same batches
+        assert isinstance(val, DeviceRayLoader) == fused and len(val) == 3
+        mse, psnr, lr = T.step(0, model, bvr, optim, sched, torch.nn.MSELoss(), scaler, val, torch.device("cuda"),
+                               split="train", perturb=False, verbose=False)
+        assert len(mse) == len(psnr) == len(lr) == 3
+        results.append((mse, psnr, [p.detach().cpu() for p in model.parameters()]))
+        if fused:                                        # one more backward: gradients come as one flat buffer
+            *_, C_ = bvr.render_volume(model, model, data.ro.cuda(), data.rd.cuda(), perturb=False, train=True)
+            ops.mse_loss(C_, data.C.cuda()).backward()
+            flat = flat_gradient(list(model.parameters()))
+            assert flat is not None and flat.numel() == sum(p.numel() for p in model.parameters())
+    ops.set_precision(None)
+    (mse_a, psnr_a, w_a), (mse_b, psnr_b, w_b) = results
+    assert_close(torch.tensor(mse_a), torch.tensor(mse_b), rtol=1e-5, atol=0, what="losses")
+    assert_close(torch.tensor(psnr_a), torch.tensor(psnr_b), rtol=1e-5, atol=1e-5, what="psnrs")
+    for k, (a, b) in enumerate(zip(w_a, w_b)):
+        assert_close(a, b, rtol=1e-4, atol=2e-6, what=f"weights after 3 steps, tensor {k}")
