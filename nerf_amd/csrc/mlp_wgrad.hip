@@ -9,7 +9,8 @@
 // plain 16-byte copies (the activation of z, which makes X, is applied on the way) and its four
 // wavefronts read the MFMA operands transposed: ds_read_b64_tr_b16 for bf16, one dword per lane
 // for the fp32 32x32x2 form.  X is the stored encoder slot, the activation of the previous
-// layer's z, or the constant 1 whose "weight" gradient is the bias gradient.  The sample range
+// layer's z; the bias gradient is the product with a constant operand (1 at position 0) that
+// never touches memory, accumulated by the workgroup of a layer's first input block.  The sample range
 // is split over workgroups; every (task, split) writes fp32 partials and a second kernel adds
 // them in a fixed order and scatters into torch-layout gradients: deterministic, no atomics.
 #include "mlp_fwd_impl.hpp"
@@ -18,10 +19,11 @@
 
 namespace nerfx {
 
-enum { WB_RAW = 0, WB_ACT = 1, WB_ONES = 2 };       // how an input tile becomes X
-enum { WM_ENC = 0, WM_CHAIN = 1, WM_BIAS = 2 };     // where an input tile's positions go
+enum { WB_RAW = 0, WB_ACT = 1 };                    // how an input tile becomes X
+enum { WM_ENC = 0, WM_CHAIN = 1 };                  // where an input tile's positions go
 enum { WO_LAYER = 0, WO_RGB = 1, WO_SIGMA = 2 };    // which weight rows a gradient tile's positions are
 constexpr int WG_SIDE = 4;                          // tiles per side of a workgroup's block
+constexpr int TASK_TILES = WG_SIDE * WG_SIDE + WG_SIDE;   // partial tiles per task: the block + one bias tile per gradient tile
 
 // A block of one layer's gradient: up to 4 gradient tiles against up to 4 input tiles.
 struct WTask {
@@ -29,6 +31,7 @@ struct WTask {
     int a_tile[WG_SIDE], a_kind[WG_SIDE], a_row0[WG_SIDE];                     // gradient tape
     int b_tile[WG_SIDE], b_kind[WG_SIDE], b_map[WG_SIDE], b_col0[WG_SIDE];     // pre-activation tape
     int w_index, b_index;                          // positions of weight and bias in the gradient list
+    int bias;                                      // this block also sums its gradient tiles over the samples
     int out_dim, enc_kind, enc_n, enc_cols, ld, chain_dim;
 };
 
@@ -66,7 +69,6 @@ static void build_tasks(const ModelPlan& p, std::vector<WTask>& out) {
             for (int t = 0; t < L.chain_tiles; ++t)
                 if (L.chain_dim > 32 * t) ins.push_back({p.tape_z_tile[src] + t, kind, WM_CHAIN, 32 * t});
         }
-        ins.push_back({0, WB_ONES, WM_BIAS, 0});
         for (size_t o = 0; o < outs.size(); o += WG_SIDE)
             for (size_t i = 0; i < ins.size(); i += WG_SIDE) {
                 WTask k{};
@@ -77,6 +79,7 @@ static void build_tasks(const ModelPlan& p, std::vector<WTask>& out) {
                     k.b_tile[s] = ins[i + s].tile; k.b_kind[s] = ins[i + s].kind; k.b_map[s] = ins[i + s].map; k.b_col0[s] = ins[i + s].col0;
                 }
                 k.w_index = w_index; k.b_index = w_index + 1; k.out_dim = out_dim;
+                k.bias = i == 0;
                 k.enc_kind = L.enc_kind; k.enc_n = L.enc_n;
                 k.enc_cols = sigma ? 0 : L.enc_cols; k.ld = sigma ? L.chain_dim : L.in_dim; k.chain_dim = L.chain_dim;
                 out.push_back(k);
@@ -94,7 +97,6 @@ template <> struct WOperand<NERFX_PREC_BF16> {
     static constexpr int CHUNK = 64;               // samples staged per step
     static constexpr int KSTEP = 16;               // samples per MFMA
     static __device__ __forceinline__ V zero() { return __builtin_bit_cast(V, s16x8(0)); }
-    static __device__ __forceinline__ V one_then_zeros() { s16x8 v(0); v[0] = 0x3F80; return __builtin_bit_cast(V, v); }
     template <int ACT>
     static __device__ __forceinline__ V act(const V& z) {
         if (ACT == NERFX_ACT_RELU) return Prec<NERFX_PREC_BF16>::relu(z);
@@ -121,6 +123,10 @@ template <> struct WOperand<NERFX_PREC_BF16> {
     static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
+    // the operand "1 at position 0 of every sample": lane (i, kh) holds 8 samples of position i
+    static __device__ __forceinline__ Frag ones(int lane) {
+        return __builtin_bit_cast(Frag, s16x8((lane & 31) == 0 ? (short)0x3F80 : (short)0));
+    }
 };
 template <> struct WOperand<NERFX_PREC_FP32> {
     using T = float;
@@ -129,7 +135,6 @@ template <> struct WOperand<NERFX_PREC_FP32> {
     static constexpr int CHUNK = 32;
     static constexpr int KSTEP = 2;
     static __device__ __forceinline__ V zero() { return V{0.0f, 0.0f, 0.0f, 0.0f}; }
-    static __device__ __forceinline__ V one_then_zeros() { return V{1.0f, 0.0f, 0.0f, 0.0f}; }
     template <int ACT>
     static __device__ __forceinline__ V act(const V& z) {
         V o;
@@ -145,10 +150,12 @@ template <> struct WOperand<NERFX_PREC_FP32> {
     static __device__ __forceinline__ void mma(f32x16& acc, const Frag& a, const Frag& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+    static __device__ __forceinline__ Frag ones(int lane) { return (lane & 31) == 0 ? 1.0f : 0.0f; }
 };
 
 // One workgroup (4 wavefronts) per (task, sample split).  Wavefront w accumulates gradient tiles
-// 2 (w >> 1), +1 against input tiles 2 (w & 1), +1.
+// 2 (w >> 1), +1 against input tiles 2 (w & 1), +1; in a block that carries the bias, the two
+// wavefronts with (w & 1) == 0 also accumulate their gradient tiles against the constant operand.
 template <int PREC, int ACT>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WTask* __restrict__ tasks, int n_tasks, int chunks_per_split,
                                                        int n_chunks, uint64_t m_pad,
@@ -162,36 +169,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WTask* __restrict__
     static_assert(TILE_BYTES == 256 * 16, "one 16-byte copy per thread per tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];    // [2 buffers][8 tiles][TILE_BYTES]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ks = blockIdx.x / n_tasks, task = blockIdx.x - ks * n_tasks;
+    // Workgroups go to the 8 XCDs round-robin by index, each XCD with its own L2.  Four consecutive
+    // (split, task) pairs are mostly blocks of ONE layer over the same samples and share their
+    // tiles, so they are given to four consecutive slots of one XCD: the second reader hits L2.
+    uint32_t vid = blockIdx.x;
+    if (vid < (gridDim.x & ~31u)) {
+        const uint32_t x = vid & 7, q = vid >> 3;
+        vid = (q >> 2) * 32 + x * 4 + (q & 3);
+    }
+    const int ks = vid / n_tasks, task = vid - ks * n_tasks;
     const WTask& tk = tasks[task];
     const int c0 = ks * chunks_per_split, c1 = min(c0 + chunks_per_split, n_chunks);
 
-    // this thread's 16 bytes of every staged tile: element tid * EPV of the tile's chunk
-    const T* src[2 * WG_SIDE];
-    int kind[2 * WG_SIDE];
+    // this thread's 16 bytes of every staged tile: a wave-uniform 64-bit base per tile (at this
+    // split's first chunk) plus one 32-bit offset, so that a load needs no address register of its own
+    // Absent tiles of a partial block alias the block's first tile (same addresses: cache hits, no
+    // extra HBM traffic) so that staging is straight-line code: eight loads in flight per thread.
+    const char* base[2 * WG_SIDE];
+    bool act_on[2 * WG_SIDE];
 #pragma unroll
     for (int s = 0; s < WG_SIDE; ++s) {
-        src[s] = gtape + (uint64_t)tk.a_tile[s] * m_pad * 32 + tid * O::EPV;
-        kind[s] = s < tk.n_a ? WB_RAW : -1;
-        src[WG_SIDE + s] = ztape + (uint64_t)tk.b_tile[s] * m_pad * 32 + tid * O::EPV;
-        kind[WG_SIDE + s] = s < tk.n_b ? tk.b_kind[s] : -1;
+        const int sa = s < tk.n_a ? s : 0, sb = s < tk.n_b ? s : 0;
+        base[s] = (const char*)(gtape + (uint64_t)tk.a_tile[sa] * m_pad * 32 + (uint64_t)c0 * O::CHUNK * 32);
+        act_on[s] = false;
+        base[WG_SIDE + s] = (const char*)(ztape + (uint64_t)tk.b_tile[sb] * m_pad * 32 + (uint64_t)c0 * O::CHUNK * 32);
+        act_on[WG_SIDE + s] = tk.b_kind[sb] == WB_ACT;
     }
-    const V ones = (tid * O::EPV) % 32 == 0 ? O::one_then_zeros() : O::zero();   // position 0 of every sample
+    const uint32_t voff = (uint32_t)tid * 16u;
     V staged[2 * WG_SIDE];
     auto stage = [&](int c) {
-        const uint64_t off = (uint64_t)c * O::CHUNK * 32;
+        const uint32_t off = voff + (uint32_t)(c - c0) * (uint32_t)(O::CHUNK * 32 * sizeof(T));   // within this split
 #pragma unroll
-        for (int s = 0; s < 2 * WG_SIDE; ++s)
-            if (kind[s] == WB_RAW || kind[s] == WB_ACT) staged[s] = *reinterpret_cast<const V*>(src[s] + off);
+        for (int s = 0; s < 2 * WG_SIDE; ++s) staged[s] = *reinterpret_cast<const V*>(base[s] + off);
     };
     auto commit = [&](int buf) {
         lds_bytes_t dst = (lds_bytes_t)smem + buf * (2 * WG_SIDE * TILE_BYTES) + tid * 16;
 #pragma unroll
         for (int s = 0; s < 2 * WG_SIDE; ++s) {
-            if (kind[s] < 0) continue;
             V v = staged[s];
-            if (kind[s] == WB_ACT) v = O::template act<ACT>(v);
-            if (kind[s] == WB_ONES) v = ones;
+            if (s >= WG_SIDE) {
+                const V a = O::template act<ACT>(v);
+                v = act_on[s] ? a : v;
+            }
             *reinterpret_cast<__attribute__((address_space(3))) V*>(dst + s * TILE_BYTES) = v;
         }
     };
@@ -199,13 +218,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WTask* __restrict__
     const int oa = 2 * (wave >> 1), ib = 2 * (wave & 1);
     const bool a_on[2] = {oa < tk.n_a, oa + 1 < tk.n_a}, b_on[2] = {ib < tk.n_b, ib + 1 < tk.n_b};
     const uint32_t lane_off = O::lane_offset(lane);
-    f32x16 acc[2][2];
+    const bool do_bias = tk.bias && (wave & 1) == 0 && a_on[0];
+    const typename O::Frag ones = O::ones(lane);
+    f32x16 acc[2][2], accb[2];
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int o = 0; o < 2; ++o) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[o][r] = 0.0f;
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[o][n][r] = 0.0f;
+    }
 
     if (c0 < c1) { stage(c0); commit(0); }
     __syncthreads();
@@ -223,18 +247,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WTask* __restrict__
                 O::mma(acc[0][1], a0, b1);
                 O::mma(acc[1][0], a1, b0);
                 O::mma(acc[1][1], a1, b1);
+                if (do_bias) {
+                    O::mma(accb[0], a0, ones);
+                    O::mma(accb[1], a1, ones);
+                }
             }
         }
         if (c + 1 < c1) commit(buf ^ 1);
         __syncthreads();
     }
-    // absent tiles were never staged: their LDS bytes are arbitrary, their products are never stored
-    float* dst = partial + ((size_t)blockIdx.x * (WG_SIDE * WG_SIDE)) * 1024 + lane * 16;
+    // products with absent (aliased) tiles are never stored
+    float* dst = partial + ((size_t)vid * TASK_TILES) * 1024 + lane * 16;
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
             if (a_on[o] && b_on[n]) *reinterpret_cast<f32x16*>(dst + ((oa + o) * WG_SIDE + ib + n) * 1024) = acc[o][n];
+    if (do_bias) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+            if (a_on[o]) *reinterpret_cast<f32x16*>(dst + (WG_SIDE * WG_SIDE + oa + o) * 1024) = accb[o];
+    }
 }
 
 // Position p of a tile written in accumulator-register order -> feature of the 32-feature tile.
@@ -243,12 +276,13 @@ __device__ __forceinline__ int tile_position_feature(int p) { return (p & 3) + 8
 // Sums the splits of one task element in split order and writes it where it belongs.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WTask* __restrict__ tasks, int n_tasks, int n_split,
                                                            const float* __restrict__ partial, GradList grads) {
-    constexpr int PER_TASK = WG_SIDE * WG_SIDE * 1024;
+    constexpr int PER_TASK = TASK_TILES * 1024;
     const int task = blockIdx.x / (PER_TASK / 256), e = (blockIdx.x % (PER_TASK / 256)) * 256 + threadIdx.x;
     const WTask& tk = tasks[task];
     const int tile = e >> 10, lane = (e >> 4) & 63, r = e & 15;
-    const int o = tile / WG_SIDE, n = tile % WG_SIDE;
-    if (o >= tk.n_a || n >= tk.n_b) return;
+    const bool bias = tile >= WG_SIDE * WG_SIDE;                     // the block's bias tiles come last
+    const int o = bias ? tile - WG_SIDE * WG_SIDE : tile / WG_SIDE, n = bias ? 0 : tile % WG_SIDE;
+    if (o >= tk.n_a || (bias ? !tk.bias : n >= tk.n_b)) return;
     const int po = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), pi = lane & 31;          // positions in the two tiles
     int row;
     if (tk.a_kind[o] == WO_LAYER) row = tk.a_row0[o] + tile_position_feature(po);
@@ -257,7 +291,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WTask* __restri
     if (row < 0 || row >= tk.out_dim) return;
     int col = -1;
     float* dst = grads.p[tk.w_index];
-    if (tk.b_map[n] == WM_BIAS) {
+    if (bias) {
         if (pi != 0) return;
         dst = grads.p[tk.b_index];
     } else if (tk.b_map[n] == WM_ENC) {
@@ -299,7 +333,7 @@ int wgrad_tasks_create(nerfx_model* m) {
 int64_t wgrad_partial_bytes(const nerfx_model* m, int prec, uint64_t m_pad) {
     int n_split, cps;
     split_plan(m->n_wtasks[prec], (int)(m_pad / chunk_samples(prec)), n_split, cps);
-    return (int64_t)n_split * m->n_wtasks[prec] * (WG_SIDE * WG_SIDE * 1024) * (int64_t)sizeof(float);
+    return (int64_t)n_split * m->n_wtasks[prec] * (TASK_TILES * 1024) * (int64_t)sizeof(float);
 }
 
 template <int PREC>
@@ -329,7 +363,7 @@ static int launch_wgrad_prec(const nerfx_model* m, uint64_t m_pad, const void* z
         default: NERFX_WGRAD(NERFX_ACT_SILU); break;
     }
 #undef NERFX_WGRAD
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(n_tasks * (WG_SIDE * WG_SIDE * 1024 / 256)), dim3(256), 0, stream, tasks,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(n_tasks * (TASK_TILES * 1024 / 256)), dim3(256), 0, stream, tasks,
                        n_tasks, n_split, partial, grads);
     return launch_status("wgrad kernels");
 }
