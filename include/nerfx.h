@@ -254,6 +254,16 @@ int nerfx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     const float* inv_scale, const float* found_inf,
                     const float* step_in, float* step_out, void* stream);
 
+/* Distillation loss of distill.py:120-130 and its gradient w.r.t. the student's outputs:
+ * loss = mean_i [ mean_j (alpha(s_sigma_i, delta_j) - alpha(t_sigma_i, delta_j))^2
+ *                 + mean_c (s_rgb_ic - t_rgb_ic)^2 ],  alpha(x, d) = 1 - exp(-x d)
+ * -- the reference broadcasts sigma.view(-1, 1) against the (n,) lengths, so every density meets
+ * every length.  sigma, delta (n); rgb (n, 3); workspace n floats; loss 1 float;
+ * g_sigma (n), g_rgb (n, 3) may be NULL. */
+int nerfx_distill_loss(const float* t_sigma, const float* t_rgb, const float* s_sigma, const float* s_rgb,
+                       const float* delta, int64_t n, float* workspace, float* loss,
+                       float* g_sigma, float* g_rgb, void* stream);
+
 /* ---- diagnostics --------------------------------------------------------------------
  * No counterpart in the reference.  In a library built with -DNERFX_STAMPS the MLP kernels
  * add per-phase cycle counts (6 x uint64: prologue, ring hand-over, MFMA runs, epilogue,

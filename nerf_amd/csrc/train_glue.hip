@@ -122,3 +122,74 @@ extern "C" int nerfx_adam_step(float* param, const float* grad, float* exp_avg, 
                        exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, inv_scale, found_inf, step_in, step_out);
     return launch_status("adam_step_kernel");
 }
+
+// ---- distillation loss (distill.py:120-130) ---------------------------------------------------
+// loss = mean_i [ mean_j (a(s_i, j) - a(t_i, j))^2 + mean_c (s_rgb_ic - t_rgb_ic)^2 ],
+// a(x_i, j) = 1 - exp(-x_i * delta_j): the reference multiplies sigma.view(-1, 1) by the (B,) vector
+// of segment lengths, so EVERY density meets EVERY length (a B x B table there; here row i is a
+// loop over j with the lengths in LDS, and the gradient is formed in the same pass).
+namespace nerfx {
+constexpr int DISTILL_THREADS = 256;
+__global__ __launch_bounds__(DISTILL_THREADS) void distill_rows_kernel(
+    const float* __restrict__ t_sigma, const float* __restrict__ t_rgb, const float* __restrict__ s_sigma,
+    const float* __restrict__ s_rgb, const float* __restrict__ delta, int n, float* __restrict__ row_loss,
+    float* __restrict__ g_sigma, float* __restrict__ g_rgb) {
+    __shared__ float d_tile[DISTILL_THREADS];
+    const int i = blockIdx.x * DISTILL_THREADS + threadIdx.x;
+    const bool on = i < n;
+    const float ts = on ? t_sigma[i] : 0.f, ss = on ? s_sigma[i] : 0.f;
+    const float inv_n = 1.0f / (float)n;
+    float sq = 0.f, gs = 0.f;
+    for (int j0 = 0; j0 < n; j0 += DISTILL_THREADS) {
+        __syncthreads();
+        d_tile[threadIdx.x] = j0 + threadIdx.x < n ? delta[j0 + threadIdx.x] : 0.f;
+        __syncthreads();
+        const int lim = min(DISTILL_THREADS, n - j0);
+        for (int j = 0; j < lim; ++j) {
+            const float d = d_tile[j];
+            const float es = expf(-ss * d), et = expf(-ts * d);
+            const float diff = (1.0f - es) - (1.0f - et);
+            sq = fmaf(diff, diff, sq);
+            gs = fmaf(diff * d, es, gs);                           // d a / d sigma = delta * exp(-sigma delta)
+        }
+    }
+    if (!on) return;
+    float rgb_sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float diff = s_rgb[3 * i + c] - t_rgb[3 * i + c];
+        rgb_sq = fmaf(diff, diff, rgb_sq);
+        if (g_rgb) g_rgb[3 * i + c] = 2.0f * diff * (inv_n / 3.0f);
+    }
+    row_loss[i] = sq * inv_n + rgb_sq * (1.0f / 3.0f);
+    if (g_sigma) g_sigma[i] = 2.0f * gs * inv_n * inv_n;
+}
+
+__global__ __launch_bounds__(MSE_THREADS) void mean_kernel(const float* __restrict__ v, int64_t n, float* __restrict__ out) {
+    __shared__ float part[MSE_THREADS / 64];
+    float acc = 0.f;
+    for (int64_t q = threadIdx.x; q < n; q += MSE_THREADS) acc += v[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < MSE_THREADS / 64; ++w) s += part[w];
+        *out = s / (float)n;
+    }
+}
+}  // namespace nerfx
+
+extern "C" int nerfx_distill_loss(const float* t_sigma, const float* t_rgb, const float* s_sigma, const float* s_rgb,
+                                  const float* delta, int64_t n, float* workspace, float* loss, float* g_sigma,
+                                  float* g_rgb, void* stream) {
+    NERFX_REQUIRE(n > 0 && n < (1 << 30), "n out of range");
+    NERFX_REQUIRE(t_sigma && t_rgb && s_sigma && s_rgb && delta && workspace && loss, "a required pointer is NULL");
+    hipLaunchKernelGGL(distill_rows_kernel, dim3((unsigned)((n + DISTILL_THREADS - 1) / DISTILL_THREADS)),
+                       dim3(DISTILL_THREADS), 0, (hipStream_t)stream, t_sigma, t_rgb, s_sigma, s_rgb, delta, (int)n,
+                       workspace, g_sigma, g_rgb);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(MSE_THREADS), 0, (hipStream_t)stream, workspace, n, loss);
+    return launch_status("distill loss kernels");
+}

@@ -1,0 +1,111 @@
+"""Distillation of a teacher field into a student (reference nerf/distill.py:22-150).
+
+Same names, arguments and order of operations as the reference's `Domain`, `VoxelSampler` and
+`distill`; teacher and student run on the HIP MLP kernels (the student with its backward), the
+loss of distill.py:123-130 and its gradient are one fused kernel, and the sampler draws on the
+device.  Note the reference's loss pairs every density with every segment length
+(`sigma.view(-1, 1) * delta` with `delta` of shape (B,)); that is kept.
+"""
+from typing import Callable, List, NamedTuple, Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.nn.utils import clip_grad_norm_
+from torch.optim import Optimizer
+
+from . import ops
+from .core.model import NeRF
+from .core.scheduler import Scheduler
+from .utils.history import History
+from .utils.pbar import tqdm
+
+GRAD_NORM_CLIP = 0.
+LOG_EVERY = 32          # steps between fetches of the device-side loss log
+
+
+class Domain(NamedTuple):
+    """Limits of the sampled volume and of the segment lengths (reference distill.py:22-27)."""
+    x: Tuple[float, float]
+    y: Tuple[float, float]
+    z: Tuple[float, float]
+    d: Tuple[float, float]
+
+
+class VoxelSampler:
+    """Random voxels of a regular grid, jittered samples inside them, random unit-ish directions
+    and segment lengths (reference distill.py:30-82).  Everything lives on `device`."""
+
+    def __init__(self, domain: Domain, voxels: int, samples: int, device=None) -> None:
+        self.domain, self.voxels, self.samples = domain, voxels, samples
+        self.batch_size = voxels * samples
+        self.device = torch.device("cuda" if device is None else device)
+        self.voxel_size = torch.tensor([abs(domain.x[1] - domain.x[0]), abs(domain.y[1] - domain.y[0]),
+                                        abs(domain.z[1] - domain.z[0])], dtype=torch.float32,
+                                       device=self.device) / voxels
+        axis = lambda d: torch.linspace(*d, steps=voxels, dtype=torch.float32, device=self.device)
+        self.rx = torch.cartesian_prod(axis(domain.x), axis(domain.y), axis(domain.z))
+
+    def __len__(self) -> int:
+        return self.rx.size(0)
+
+    def sample(self) -> Tuple[Tensor, Tensor, Tensor]:
+        """-> rx (B, 3), rd (B, 3), delta (B,) with B = voxels * samples."""
+        idxs = torch.randint(len(self), (self.voxels,), device=self.device)
+        rx = self.rx[idxs.repeat_interleave(self.samples, dim=0)]
+        rx = rx + torch.randn_like(rx) * (.5 * self.voxel_size[None, :])
+        rd = torch.rand((self.batch_size, 3), dtype=torch.float32, device=self.device)
+        rd = rd / torch.linalg.norm(rd, dim=-1, keepdim=True)
+        delta = torch.rand((self.batch_size,), dtype=torch.float32, device=self.device)
+        delta = self.domain.d[0] + abs(self.domain.d[1] - self.domain.d[0]) * delta
+        return rx, rd, delta
+
+
+def distill(teacher: NeRF, student: NeRF, sampler: VoxelSampler, optim: Optimizer, scheduler: Scheduler, scaler,
+            iterations: Optional[int] = 100, callbacks: Optional[List[Callable[[int, History], None]]] = [],
+            verbose: bool = True) -> History:
+    """Train `student` to reproduce `teacher`'s opacity and colour on sampled points (reference
+    distill.py:85-147).  The per-step loss stays on the device and is fetched every LOG_EVERY
+    steps; callbacks therefore see the history up to the last fetch (always complete at the end
+    and whenever the number of callbacks is non-zero and a fetch is due)."""
+    d = next(teacher.parameters()).device
+    H = History()
+    log = torch.zeros((iterations,), dtype=torch.float32, device=d)
+    fetched = 0
+
+    def fetch(upto: int) -> None:
+        nonlocal fetched
+        for value in log[fetched:upto].tolist():
+            H.train.append((value, None))
+        fetched = max(fetched, upto)
+
+    steps = tqdm(range(iterations), desc="[NeRF] Distill Step", disable=not verbose)
+    for step in steps:
+        rx, rd, delta = sampler.sample()
+        rx, rd, delta = rx.to(d), rd.to(d), delta.to(d)
+
+        with torch.autocast("cuda", enabled=scaler.is_enabled()):
+            with torch.no_grad():
+                t_sigma, t_rgb = teacher(rx, rd)
+            s_sigma, s_rgb = student(rx, rd)
+            loss = ops.distill_loss(s_sigma, s_rgb, t_sigma, t_rgb, delta)
+
+        scaler.scale(loss).backward()
+        scaler.unscale_(optim)
+        if GRAD_NORM_CLIP > 0.:
+            clip_grad_norm_(student.parameters(), GRAD_NORM_CLIP)
+        scaler.step(optim)
+        scaler.update()
+        optim.zero_grad(set_to_none=True)
+        scheduler.step()
+
+        log[step] = loss.detach()
+        H.lr.append(scheduler.lr)
+        if callbacks or (step + 1) % LOG_EVERY == 0 or step + 1 == iterations:
+            fetch(step + 1)
+            steps.set_postfix(loss=f"{H.train[-1][0]:.2e}")
+        for callback in callbacks:
+            callback(step, H)
+    return H
+
+
+NeRF.distill = distill

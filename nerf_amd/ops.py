@@ -568,3 +568,35 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
     with torch.cuda.device(param.device):
         check(lib.nerfx_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lr, beta1, beta2, eps,
                                   weight_decay, _p(inv_scale), _p(found_inf), _p(step_in), _p(step_out), _stream()))
+
+
+class _DistillLossFunction(torch.autograd.Function):
+    """The distillation loss with its gradient w.r.t. the student's outputs formed in the forward pass."""
+
+    @staticmethod
+    def forward(ctx, s_sigma, s_rgb, t_sigma, t_rgb, delta):
+        n = s_sigma.numel()
+        dev = s_sigma.device
+        ws, loss = torch.empty((n,), device=dev), torch.empty((1,), device=dev)
+        g_sigma, g_rgb = torch.empty_like(s_sigma), torch.empty_like(s_rgb)
+        with torch.cuda.device(dev):
+            check(lib.nerfx_distill_loss(_p(t_sigma), _p(t_rgb), _p(s_sigma), _p(s_rgb), _p(delta), n, _p(ws), _p(loss),
+                                         _p(g_sigma), _p(g_rgb), _stream()))
+        ctx.save_for_backward(g_sigma, g_rgb)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        g_sigma, g_rgb = ctx.saved_tensors
+        return g_sigma * g, g_rgb * g, None, None, None
+
+
+def distill_loss(s_sigma: Tensor, s_rgb: Tensor, t_sigma: Tensor, t_rgb: Tensor, delta: Tensor) -> Tensor:
+    """Loss of reference distill.py:123-130 (0-dim tensor; differentiable w.r.t. the student's outputs)."""
+    s_sigma, t_sigma, delta = (_dev(x, n).reshape(-1) for x, n in ((s_sigma, "s_sigma"), (t_sigma.detach(), "t_sigma"),
+                                                                  (delta.detach(), "delta")))
+    s_rgb, t_rgb = _dev(s_rgb, "s_rgb").reshape(-1, 3), _dev(t_rgb.detach(), "t_rgb").reshape(-1, 3)
+    n = s_sigma.numel()
+    assert t_sigma.numel() == n and delta.numel() == n and s_rgb.shape[0] == n and t_rgb.shape[0] == n, \
+        "sigma, delta (n) and rgb (n, 3) must agree on n"
+    return _DistillLossFunction.apply(s_sigma, s_rgb, t_sigma, t_rgb, delta)

@@ -324,6 +324,29 @@ def frame_to_uint8(frame: Tensor):
     return frame.numpy().astype("uint8")
 
 
+def distill_loss(s_sigma: Tensor, s_rgb: Tensor, t_sigma: Tensor, t_rgb: Tensor, delta: Tensor) -> Tensor:
+    """distill.py:123-130, including its (B, 1) x (B,) broadcast of densities against lengths."""
+    t_alpha = 1. - torch.exp(-t_sigma.view(-1, 1) * delta)
+    s_alpha = 1. - torch.exp(-s_sigma.view(-1, 1) * delta)
+    loss_alpha = torch.mean((s_alpha - t_alpha) ** 2, dim=-1)
+    loss_rgb = torch.mean((s_rgb - t_rgb) ** 2, dim=-1)
+    return torch.mean(loss_alpha + loss_rgb, dim=0)
+
+
+def distill_step(teacher: "Model", student: "Model", rx: Tensor, rd: Tensor, delta: Tensor,
+                 optim: torch.optim.Optimizer):
+    """One iteration of distill.py:117-138 without the scaler.  -> (loss, student grads)."""
+    with torch.no_grad():
+        t_sigma, t_rgb = teacher(rx, rd)
+    s_sigma, s_rgb = student(rx, rd)
+    loss = distill_loss(s_sigma, s_rgb, t_sigma, t_rgb, delta)
+    optim.zero_grad(set_to_none=True)
+    loss.backward()
+    grads = {k: v.grad.detach().clone() for k, v in student.params.items() if v.grad is not None}
+    optim.step()
+    return loss.detach(), grads
+
+
 def train_step(params: Params, enc_x, enc_d, activ, resid, ro, rd, target, tn, tf,
                n_coarse, n_fine, u_coarse, u_fine, optim: torch.optim.Optimizer):
     """train.py:75-86 with the GradScaler disabled: one render(train=True) + MSE

@@ -182,3 +182,19 @@ def test_frame_to_uint8_truncates():
     u8 = O.frame_to_uint8(g["depth"])
     assert u8.dtype.name == "uint8" and u8.max() <= 255
     assert (u8 == g["depth"].floor().to(torch.uint8).numpy()).all()
+
+
+def test_g11_distill_three_iterations():
+    """The oracle's distillation step replays the reference's `distill` (distill.py:85-147)."""
+    meta, g = load_golden("g11_distill")
+    teacher = oracle_model(meta["teacher"], g)
+    student = oracle_model(meta["student"], g, requires_grad=True)
+    optim = torch.optim.Adam(list(student.params.values()), lr=meta["lr"], eps=meta["eps"])
+    for k in range(meta["iters"]):
+        loss, _ = O.distill_step(teacher, student, g[f"rx{k}"], g[f"rd{k}"], g[f"delta{k}"], optim)
+        assert_close(loss.double(), g["losses"][k], rtol=1e-5, atol=0, what=f"loss {k}")
+    for name, p in student.params.items():
+        assert_close(p.detach(), g["after." + name], rtol=1e-4, atol=1e-6, what=name)
+    # sampler fixture: grid = cartesian product of linspaces, lengths inside the domain
+    assert g["vs_grid"].shape == (64, 3) and g["vs_rx"].shape == (32, 3) and g["vs_delta"].shape == (32,)
+    assert_close(g["vs_rd"].norm(dim=-1), torch.ones(32), rtol=1e-6, atol=0, what="unit directions")

@@ -322,8 +322,52 @@ def g10_camera():
     save("g10_camera", dict(cam_angle_x=cam_angle_x, sizes=[list(s) for s in sizes], pose_ids=[0, 3, 5]), **out)
 
 
+def g11_distill():
+    """nerf.distill.distill driven for three iterations with a sampler that replays fixed draws."""
+    import nerf.distill as ref_distill
+    teacher, tmeta, _ = build_model("base")
+    student, smeta, _ = build_model("student")
+    student.train()
+    g = torch.Generator().manual_seed(111)
+    B, iters = 48, 3
+    draws = []
+    for _ in range(iters):
+        rx = (torch.rand(B, 3, generator=g) * 2 - 1) * 4.0
+        rd = torch.rand(B, 3, generator=g)
+        rd = rd / torch.linalg.norm(rd, dim=-1, keepdim=True)
+        delta = 0.002 + 0.05 * torch.rand(B, generator=g)
+        draws.append((rx, rd, delta))
+
+    class Replay:
+        def __init__(self):
+            self.k = 0
+
+        def sample(self):
+            out = draws[self.k]
+            self.k += 1
+            return out
+
+    optim = torch.optim.Adam(student.parameters(), lr=5e-4, eps=1e-8)
+    sched = IndendityScheduler(optim, iters, 5e-4)
+    scaler = torch.cuda.amp.GradScaler(enabled=False)
+    H = ref_distill.distill(teacher, student, Replay(), optim, sched, scaler, iterations=iters, verbose=False)
+    out = {}
+    for k, (rx, rd, delta) in enumerate(draws):
+        out.update({f"rx{k}": rx, f"rd{k}": rd, f"delta{k}": delta})
+    out["losses"] = np.array([l for l, _ in H.train], dtype=np.float64)
+    for k, p in student.named_parameters():
+        out["after." + k] = p.detach().clone()
+    # the sampler's own shapes and ranges
+    torch.manual_seed(5); np.random.seed(5)
+    dom = ref_distill.Domain(x=(-4, 4), y=(-4, 4), z=(-4, 4), d=(0.00625, 0.00625))
+    vs = ref_distill.VoxelSampler(dom, voxels=4, samples=8)
+    rx, rd, delta = vs.sample()
+    out.update(vs_grid=vs.rx, vs_voxel_size=vs.voxel_size, vs_rx=rx, vs_rd=rd, vs_delta=delta)
+    save("g11_distill", dict(teacher=tmeta, student=smeta, iters=iters, B=B, lr=5e-4, eps=1e-8), **out)
+
+
 ALL = (g1_sampling, g2_encodings, g3_mlp, g4_composite, g5_pdf, g6_render, g7_train, g8_infer,
-       g9_schedulers, g10_camera)
+       g9_schedulers, g10_camera, g11_distill)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
