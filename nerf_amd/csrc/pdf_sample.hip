@@ -9,7 +9,6 @@
 namespace nerfx {
 
 constexpr int K4_MAX = 256;                       // max nc and max nf
-constexpr int K4_SORT = 512;                      // pow2 >= nc + nf
 
 // cumsum in double, rounded to fp32 per element: what torch's CPU cumsum does.
 __device__ __forceinline__ double wave_incl_sum(double v, int lane) {
@@ -44,19 +43,22 @@ __device__ __forceinline__ int lower_bound(const float* a, int n, float x) {
     return lo;
 }
 
+// R = values of each row a lane holds: the kernel is instantiated for rows of up to 64, 128 and
+// 256 samples, so the usual 64 + 64 case carries no loops or predicates for longer rows.
+template <int R>
 __global__ __launch_bounds__(64) void pdf_sample_kernel(
     const float* __restrict__ t_c, const float* __restrict__ w_c, int64_t n_rays, int nc, int nf,
     const float* __restrict__ u_g, float* __restrict__ t_sorted, float* __restrict__ cdf_out,
     int64_t* __restrict__ idx_out, float* __restrict__ t_pdf_out) {
-    __shared__ float tc[K4_MAX], cdf[K4_MAX], bins[K4_MAX], tp[K4_MAX], srt[K4_SORT];
-    __shared__ int guess[K4_MAX], hist[K4_MAX + 1];
+    constexpr int ROW = 64 * R;
+    __shared__ float tc[ROW], cdf[ROW], bins[ROW], tp[ROW], srt[2 * ROW];
+    __shared__ int guess[ROW], hist[ROW + 1];
     __shared__ int unsorted;
     const int lane = threadIdx.x;
     const int nb = nc - 1;                         // bins (mid points) and cdf entries
     const int nw = nc - 2;                         // interior weights
     // The per-ray work is a chain of dependent steps, so a wavefront hides HBM latency only by
     // loading the NEXT ray's inputs (registers) before it starts on the current one.
-    constexpr int R = K4_MAX / 64;
     float t_cur[R], w_cur[R], u_cur[R], t_nxt[R], w_nxt[R], u_nxt[R];
     auto fetch = [&](int64_t ray, float (&tr)[R], float (&wr)[R], float (&ur)[R]) {
 #pragma unroll
@@ -89,15 +91,21 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
         const float total = part;
         __syncthreads();
         double carry = 0.0;
-        for (int k0 = 0; k0 < nw; k0 += 64) {      // cdf[k + 1] = sum_{j <= k} pdf_j
-            const int k = k0 + lane;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {              // cdf[k + 1] = sum_{j <= k} pdf_j
+            const int k = 64 * q + lane;
+            if (64 * q >= nw) break;
             const float pdf = k < nw ? srt[k + 1] / total : 0.f;
             const double inc = wave_incl_sum((double)pdf, lane) + carry;
             if (k < nw) cdf[k + 1] = (float)inc;
             carry = __shfl(inc, 63, 64);
         }
         if (lane == 0) cdf[0] = 0.f;
-        for (int i = lane; i < nb; i += 64) bins[i] = __fmul_rn(0.5f, __fadd_rn(tc[i], tc[i + 1]));
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int i = lane + 64 * q;
+            if (i < nb) bins[i] = __fmul_rn(0.5f, __fadd_rn(tc[i], tc[i + 1]));
+        }
         __syncthreads();
         if (cdf_out)
             for (int i = lane; i < nb; i += 64) cdf_out[ray * nb + i] = cdf[i];
@@ -121,10 +129,12 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
         }
         __syncthreads();
         // -- merge (ray.py:223) ---------------------------------------------------
-        for (int j = lane; j + 1 < nf; j += 64)
-            if (!(tp[j] <= tp[j + 1])) unsorted = 1;                   // benign race: all write 1
-        for (int i = lane; i + 1 < nc; i += 64)
-            if (!(tc[i] <= tc[i + 1])) unsorted = 1;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int j = lane + 64 * q;
+            if (j + 1 < nf && !(tp[j] <= tp[j + 1])) unsorted = 1;    // benign race: all write 1
+            if (j + 1 < nc && !(tc[j] <= tc[j + 1])) unsorted = 1;
+        }
         __syncthreads();
         const int n = nc + nf;
         float* out = t_sorted + ray * n;
@@ -135,9 +145,14 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
             // or idx_j + 1: start there and let two short scans settle ties and roundings.
             // The coarse values then fill the slots left over: tc[i] goes to i + #{j : r_j <= i},
             // a histogram of r followed by a running sum.
-            for (int i = lane; i <= nc; i += 64) hist[i] = 0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) hist[lane + 64 * q] = 0;
+            if (lane == 0) hist[ROW] = 0;
             __syncthreads();
-            for (int j = lane; j < nf; j += 64) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int j = lane + 64 * q;
+                if (j >= nf) continue;
                 const float v = tp[j];
                 int r = min(guess[j], nc);
                 while (r < nc && tc[r] <= v) ++r;
@@ -147,8 +162,10 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
             }
             __syncthreads();
             int carry = 0;                                           // #{j : r_j <= i}: inclusive running sum of hist
-            for (int i0 = 0; i0 < nc; i0 += 64) {
-                const int i = i0 + lane;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int i = 64 * q + lane;
+                if (64 * q >= nc) break;
                 int inc = i < nc ? hist[i] : 0;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
@@ -208,8 +225,10 @@ extern "C" int nerfx_pdf_sample(const float* t_c, const float* w_c, int64_t n_ra
     if (n_rays == 0) return 0;
     NERFX_REQUIRE(t_c && w_c && t_sorted, "t_c / w_c / t_sorted is NULL");
     const int grid = (int)std::min<int64_t>(n_rays, 256 * 32);
-    hipLaunchKernelGGL(pdf_sample_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, t_c, w_c, n_rays,
-                       nc, nf, u, t_sorted, cdf, idx, t_pdf);
+    const int longest = std::max(nc, nf);
+    auto kern = longest <= 64 ? pdf_sample_kernel<1> : (longest <= 128 ? pdf_sample_kernel<2> : pdf_sample_kernel<4>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, (hipStream_t)stream, t_c, w_c, n_rays, nc, nf, u, t_sorted,
+                       cdf, idx, t_pdf);
     return launch_status("pdf_sample_kernel");
 }
 
