@@ -12,7 +12,7 @@ namespace nerfx {
 constexpr int K3_WAVES = 4;                      // waves per workgroup
 constexpr float K3_EPS = 1e-10f;                 // renderer.py:48
 
-// A ray is owned by a GROUP of LPR consecutive lanes (LPR = 32: two rays per wavefront, 64: one);
+// A ray is owned by a GROUP of LPR consecutive lanes (LPR = 16: four rays per wavefront, 32: two, 64: one);
 // all cross-lane steps stay inside the group.
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
@@ -145,17 +145,18 @@ __global__ __launch_bounds__(64 * K3_WAVES) void composite_fwd_kernel(
         const int64_t ray = min(ray0 + lane / LPR, n_rays - 1);
         const bool mine = ray0 + lane / LPR < n_rays;
         RaySlice<EPL, LPR> s;
+        const int64_t base = ray * n + gl * EPL;
+        float w[EPL], c[3 * EPL];
+        // colours are requested together with the densities: one round trip to HBM per ray, not two
+        if (rgb) load_slice<3 * EPL>(rgb + base * 3, 3 * min(max(n - gl * EPL, 0), EPL), n == EPL * LPR, c);
         s.load(sigma, t, rd, delta, ray, n, gl);
         float T[EPL];
         s.transmittance(T, gl);
-        const int64_t base = ray * n + gl * EPL;
-        float w[EPL], c[3 * EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) w[e] = s.alpha[e] * T[e];        // renderer.py:52
         if (weights && mine) store_slice<EPL>(weights + base, s.valid, s.vec, w);
         float r = 0.f, g = 0.f, b = 0.f, d = 0.f;
         if (rgb) {
-            load_slice<3 * EPL>(rgb + base * 3, 3 * s.valid, s.vec, c);
 #pragma unroll
             for (int e = 0; e < EPL; ++e)
                 if (e < s.valid) { r += w[e] * c[3 * e]; g += w[e] * c[3 * e + 1]; b += w[e] * c[3 * e + 2]; }
@@ -190,15 +191,18 @@ __global__ __launch_bounds__(64 * K3_WAVES) void composite_bwd_kernel(
         const int64_t ray = min(ray0 + lane / LPR, n_rays - 1);
         const bool mine = ray0 + lane / LPR < n_rays;
         RaySlice<EPL, LPR> s;
+        const int64_t base = ray * n + gl * EPL;
+        float w[EPL], G[EPL], wG[EPL], c[3 * EPL], gw[EPL];
+        // every input of the ray is requested up front: one round trip to HBM per ray
+        const int live = min(max(n - gl * EPL, 0), EPL);
+        const bool whole = n == EPL * LPR;
+        if (rgb) load_slice<3 * EPL>(rgb + base * 3, 3 * live, whole, c);
+        if (g_weights) load_slice<EPL>(g_weights + base, live, whole, gw);
+        const float gr = g_rgb_map ? g_rgb_map[3 * ray] : 0.f, gg = g_rgb_map ? g_rgb_map[3 * ray + 1] : 0.f,
+                    gb = g_rgb_map ? g_rgb_map[3 * ray + 2] : 0.f, gd = g_depth ? g_depth[ray] : 0.f;
         s.load(sigma, t, rd, delta, ray, n, gl);
         float T[EPL];
         s.transmittance(T, gl);
-        const float gr = g_rgb_map ? g_rgb_map[3 * ray] : 0.f, gg = g_rgb_map ? g_rgb_map[3 * ray + 1] : 0.f,
-                    gb = g_rgb_map ? g_rgb_map[3 * ray + 2] : 0.f, gd = g_depth ? g_depth[ray] : 0.f;
-        const int64_t base = ray * n + gl * EPL;
-        float w[EPL], G[EPL], wG[EPL], c[3 * EPL], gw[EPL];
-        if (rgb) load_slice<3 * EPL>(rgb + base * 3, 3 * s.valid, s.vec, c);
-        if (g_weights) load_slice<EPL>(g_weights + base, s.valid, s.vec, gw);
         float lane_total = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void segment_lengths_kernel(const float* __res
 }
 
 static int composite_grid(int64_t n_rays, int n) {
-    const int per_block = K3_WAVES * (n <= 256 ? 2 : 1);             // rays in flight per workgroup
+    const int per_block = K3_WAVES * (n > 256 ? 1 : (n > 32 && n <= 64 ? 4 : 2));   // rays in flight per workgroup
     return (int)std::min<int64_t>((n_rays + per_block - 1) / per_block, 256 * 8);
 }
 
@@ -249,13 +253,13 @@ static int composite_grid(int64_t n_rays, int n) {
 
 using namespace nerfx;
 
-// Lanes per ray and samples per lane for n samples: two rays per wavefront up to 256 samples
-// (16-byte slices when n is 128 or 256), one ray per wavefront beyond.
+// Lanes per ray and samples per lane for n samples: four rays per wavefront for 33..64 samples
+// (the coarse pass), two up to 256 samples (16-byte slices when n is 64, 128 or 256), one beyond.
 #define K3_CASE(EPL, LPR, KERNEL, ...) hipLaunchKernelGGL((KERNEL<EPL, LPR>), __VA_ARGS__)
 #define K3_DISPATCH(N, KERNEL, ...)                                                                \
     do {                                                                                           \
         if ((N) <= 32) K3_CASE(1, 32, KERNEL, __VA_ARGS__);                                        \
-        else if ((N) <= 64) K3_CASE(2, 32, KERNEL, __VA_ARGS__);                                   \
+        else if ((N) <= 64) K3_CASE(4, 16, KERNEL, __VA_ARGS__);                                   \
         else if ((N) <= 96) K3_CASE(3, 32, KERNEL, __VA_ARGS__);                                   \
         else if ((N) <= 128) K3_CASE(4, 32, KERNEL, __VA_ARGS__);                                  \
         else if ((N) <= 192) K3_CASE(6, 32, KERNEL, __VA_ARGS__);                                  \
