@@ -309,10 +309,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WTask* __restri
     else dst[(size_t)row * tk.ld + col] = sum;
 }
 
-// Sample splits for a launch: enough workgroups to fill the device twice over.
+// Sample splits for a launch: as many as fit in WGRAD_ROUNDS full rounds of resident workgroups
+// (two per CU), never one more -- a few workgroups left over would run a round of their own.
+#ifndef WGRAD_ROUNDS
+#define WGRAD_ROUNDS 2
+#endif
+static int resident_workgroups() {
+    static thread_local int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        slots = 2 * cus;
+    }
+    return slots;
+}
 static void split_plan(int n_tasks, int n_chunks, int& n_split, int& chunks_per_split) {
     if (n_chunks <= 0 || n_tasks <= 0) { n_split = 0; chunks_per_split = 1; return; }
-    int want = (2048 + n_tasks - 1) / n_tasks;
+    int want = WGRAD_ROUNDS * resident_workgroups() / n_tasks;
     want = std::max(1, std::min(want, n_chunks));
     chunks_per_split = (n_chunks + want - 1) / want;
     n_split = (n_chunks + chunks_per_split - 1) / chunks_per_split;
