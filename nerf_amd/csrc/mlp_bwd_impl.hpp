@@ -34,7 +34,7 @@ __device__ __forceinline__ float activation_slope(float z) {
     if (ACT == NERFX_ACT_RELU) return z > 0.0f ? 1.0f : 0.0f;
     if (ACT == NERFX_ACT_LEAKY_RELU) return z > 0.0f ? 1.0f : 0.01f;
     if (ACT == NERFX_ACT_SILU) {
-        const float s = 1.0f / (1.0f + Prec<PREC>::expneg(z));
+        const float s = Prec<PREC>::sigmoid(z);
         return s * (1.0f + z * (1.0f - s));
     }
     return 1.0f;
