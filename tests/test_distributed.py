@@ -81,6 +81,26 @@ def _grad_job(rank, world):
     return [p.grad.clone() for p in net.parameters()], [p.detach().clone() for p in net.parameters()]
 
 
+def _flat_grad_job(rank, world):
+    """As _grad_job, but the gradients are views of ONE buffer, as the HIP backward returns them:
+    the all-reduce must then run in place on that buffer."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    g = torch.Generator().manual_seed(100)
+    x, y = torch.rand(8, 5, generator=g), torch.rand(8, 3, generator=g)
+    s, e = D.shard_bounds(8, rank, world)
+    torch.nn.functional.mse_loss(net(x[s:e]), y[s:e]).backward()
+    params = list(net.parameters())
+    sizes = [p.numel() for p in params]
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    for p, v in zip(params, flat.split(sizes)):
+        p.grad = v.view(p.shape)
+    assert D.flat_gradient(params) is not None
+    D.average_gradients(net)
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, flat.split(sizes))), "in place"
+    return flat.clone()
+
+
 def test_gradient_average_equals_full_batch():
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
@@ -96,6 +116,18 @@ def test_gradient_average_equals_full_batch():
             assert torch.allclose(got, p.grad, rtol=1e-6, atol=1e-8)
     for a, b in zip(out[0][0], out[1][0]):
         assert torch.equal(a, b)                   # identical on both ranks (the scaler's inf check relies on it)
+
+
+def test_flat_gradient_average_in_place():
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    g = torch.Generator().manual_seed(100)
+    x, y = torch.rand(8, 5, generator=g), torch.rand(8, 3, generator=g)
+    torch.nn.functional.mse_loss(net(x), y).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    out = run(_flat_grad_job)
+    assert torch.equal(out[0], out[1])
+    assert torch.allclose(out[0], want, rtol=1e-6, atol=1e-8)
 
 
 def test_single_process_is_a_no_op():
