@@ -7,6 +7,7 @@ int launch_mlp_fp32(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_bigenc(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_fp32_bigenc(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
+int launch_mlp_bf16_bigenc_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
 int launch_mlp_fp32_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_train(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_fp32_train(int activ, int wt, const MlpArgs& a, hipStream_t s);
@@ -62,6 +63,8 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
     }
     // encoders that fit the kernels' register cache take the fast instantiations
     const bool big = a.ex_units > ENC_BLOCK || a.ed_units > ENC_BLOCK;
+    if (big && precision == NERFX_PREC_BF16 && p.wt == 8 && p.desc.resid && (p.hd == 2 || p.hd == 4))
+        return launch_mlp_bf16_bigenc_fixed(p.desc.activ, p.hd, a, (hipStream_t)stream);
     if (!big && p.wt == 8 && p.desc.resid && (p.hd == 2 || p.hd == 4))          // compile-time depth
         return (precision == NERFX_PREC_BF16 ? launch_mlp_bf16_fixed : launch_mlp_fp32_fixed)(p.desc.activ, p.hd, a, (hipStream_t)stream);
     auto launch = precision == NERFX_PREC_BF16 ? (big ? launch_mlp_bf16_bigenc : launch_mlp_bf16)

@@ -702,11 +702,11 @@ static int launch_width(int wt, const MlpArgs& a, hipStream_t s) {
 }
 
 // Width-256 models with the skip connection and depth 4 or 8 (the reference's configurations).
-template <int PREC, class RG, bool TRAIN = false>
+template <int PREC, class RG, bool TRAIN = false, bool BIGENC = false>
 static int launch_fixed_depth(int activ, int hd, const MlpArgs& a, hipStream_t s) {
 #define NERFX_FIXED(ACT_)                                                                  \
     case ACT_:                                                                             \
-        return hd == 2 ? launch_cfg<PREC, 8, RG, ACT_, false, 2, TRAIN>(a, s) : launch_cfg<PREC, 8, RG, ACT_, false, 4, TRAIN>(a, s);
+        return hd == 2 ? launch_cfg<PREC, 8, RG, ACT_, BIGENC, 2, TRAIN>(a, s) : launch_cfg<PREC, 8, RG, ACT_, BIGENC, 4, TRAIN>(a, s);
     switch (activ) {
         NERFX_FIXED(NERFX_ACT_RELU)
         NERFX_FIXED(NERFX_ACT_LEAKY_RELU)
