@@ -152,9 +152,22 @@ def searchsorted_right(cdf: Tensor, u: Tensor) -> Tensor:
 _ACTS = {"ReLU": _lib.ACT_RELU, "LeakyReLU": _lib.ACT_LEAKY_RELU, "SiLU": _lib.ACT_SILU}
 
 
+def child(module, *names):
+    """Submodule by child names; works for nn.Sequential and for its scripted form alike
+    (a ScriptModule has no __getitem__)."""
+    for name in names:
+        module = dict(module.named_children())[name]
+    return module
+
+
+def activation_name(module) -> str:
+    act = child(module, "fc_1", "0", "1")
+    return getattr(act, "original_name", type(act).__name__)       # ScriptModule or nn.Module
+
+
 def _activation_code(module) -> int:
-    act = module.fc_1[0][1]
-    name = getattr(act, "original_name", type(act).__name__)      # ScriptModule or nn.Module
+    act = child(module, "fc_1", "0", "1")
+    name = activation_name(module)
     if name not in _ACTS:
         raise NotImplementedError(f"hidden activation {name} has no HIP kernel (ReLU / LeakyReLU / SiLU)")
     if name == "LeakyReLU" and abs(float(getattr(act, "negative_slope", 0.01)) - 0.01) > 1e-12:

@@ -52,3 +52,42 @@ def product_model(meta, arrays, prefix="", device="cuda"):
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected and all(k.startswith("phi_") for k in missing)
     return m.to(device)
+
+
+# ---- a scriptable stand-in for a model file written by the reference (test infrastructure) ----
+class _ScriptableEncoder(torch.nn.Module):
+    def __init__(self, freq_bands):
+        super().__init__()
+        self.register_buffer("freq_bands", freq_bands)
+
+    def forward(self, v):
+        return O.encode_positional(v, self.freq_bands)
+
+
+class ScriptableField(torch.nn.Module):
+    """Submodule names, parameter shapes and forward of the reference's NeRF (model.py:39-78) in plain
+    torch ops, so that `torch.jit.script` accepts it: what a `*.model.ts` of the reference holds."""
+
+    def __init__(self, n_x: int, n_d: int, width: int, depth: int, resid: bool):
+        super().__init__()
+        from torch.nn import Linear, ReLU, Sequential
+        self.phi_x = _ScriptableEncoder(O.positional_freq_bands(n_x))
+        self.phi_d = _ScriptableEncoder(O.positional_freq_bands(n_d))
+        e_x, e_d, half = 3 + 6 * n_x, 3 + 6 * n_d, depth // 2
+        self.resid = resid
+        blk = lambda i, o: Sequential(Linear(i, o), ReLU())
+        self.fc_1 = Sequential(blk(e_x, width), *(blk(width, width) for _ in range(half - 1)))
+        self.fc_2 = Sequential(blk(width + (e_x if resid else 0), width), *(blk(width, width) for _ in range(half - 1)))
+        self.sigma = Sequential(Linear(width, 1))
+        self.features = Linear(width, width)
+        self.rgb = Sequential(Linear(e_d + width, width // 2), ReLU(), Linear(width // 2, 3))
+
+    def forward(self, rx, rd):
+        px, pd = self.phi_x(rx), self.phi_d(rd)
+        x = self.fc_1(px)
+        if self.resid:
+            x = torch.cat((px, x), dim=-1)
+        x = self.fc_2(x)
+        sigma = O.shifted_softplus(self.sigma(x)).view(-1)
+        rgb = O.widened_sigmoid(self.rgb(torch.cat((pd, self.features(x)), dim=-1)))
+        return sigma, rgb

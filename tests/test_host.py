@@ -130,3 +130,40 @@ def test_install_as_alias():
     assert A is B
     for k in [k for k in sys.modules if k.startswith("nerf_alias_for_test")]:
         del sys.modules[k]
+
+
+def test_model_file_round_trip(tmp_path):
+    """save / load keep constructor arguments, parameters and encoder buffers; the file holds
+    nothing executable (read with weights_only=True)."""
+    import nerf_amd.io as io
+    from nerf_amd.core import FourierFeatures, NeRF, PositionalEncoding
+    torch.manual_seed(3)
+    for model in (NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 4), 32, 2, torch.nn.SiLU, False),
+                  NeRF(FourierFeatures(3, 16, 8.0), PositionalEncoding(3, 6), 64, 4)):
+        path = str(tmp_path / "m.nerfx")
+        io.save(model, path)
+        back = io.load(path, device="cpu")
+        assert io.describe(back) == io.describe(model)
+        assert back.width == model.width and back.depth == model.depth and back.resid == model.resid
+        a, b = model.state_dict(), back.state_dict()
+        assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    with pytest.raises(Exception):
+        torch.save({"format": "other"}, str(tmp_path / "x"))
+        io.load(str(tmp_path / "x"), device="cpu")
+
+
+def test_from_torchscript_reads_a_scripted_field(tmp_path):
+    """A scripted module with the reference's layout (what its *.model.ts files hold) becomes a
+    nerf_amd NeRF with the same architecture and weights."""
+    import nerf_amd.io as io
+    from helpers import ScriptableField
+    torch.manual_seed(4)
+    ref = ScriptableField(6, 4, 32, 4, True)
+    path = str(tmp_path / "NeRF_test.model.ts")
+    torch.jit.save(torch.jit.script(ref), path)
+    nerf = io.from_torchscript(path, device="cpu")
+    assert io.describe(nerf) == {"phi_x": {"kind": "positional", "n": 6}, "phi_d": {"kind": "positional", "n": 4},
+                                 "width": 32, "depth": 4, "activ": "ReLU", "resid": True}
+    want = ref.state_dict()
+    got = nerf.state_dict()
+    assert set(want) == set(got) and all(torch.equal(want[k], got[k]) for k in want)
