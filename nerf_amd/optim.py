@@ -48,6 +48,27 @@ class Adam(torch.optim.Optimizer):
         state["which"] = 0
         state["flat_grad"] = torch.zeros_like(flat)                 # used only when the gradients are not flat
 
+    def _ensure_flat(self, group) -> None:
+        """Parameters must still be the views made by _flatten (a later `module.to(...)`,
+        `load_state_dict(assign=True)` or `p.data = ...` replaces them): if not, adopt the current
+        values into the flat buffer again and keep the moments."""
+        params = group["params"]
+        state = self.state[params[0]]
+        flat = state["flat_param"]
+        ptr = flat.data_ptr()
+        for p, n in zip(params, state["sizes"]):
+            if p.data_ptr() != ptr or p.device != flat.device or not p.is_contiguous():
+                break
+            ptr += 4 * n
+        else:
+            return
+        if any(p.device != flat.device or p.dtype != torch.float32 for p in params):
+            raise RuntimeError("nerf_amd.optim.Adam: parameters moved to another device or dtype after construction")
+        with torch.no_grad():
+            for p, v in zip(params, flat.split(state["sizes"])):
+                v.copy_(p.detach().reshape(-1))
+                p.data = v.view(p.shape)
+
     @property
     def steps_applied(self) -> int:
         """Number of updates actually applied to the first group (synchronises)."""
@@ -67,6 +88,7 @@ class Adam(torch.optim.Optimizer):
             state = self.state[params[0]]
             if all(p.grad is None for p in params):
                 continue
+            self._ensure_flat(group)
             grad = flat_gradient(params)
             if grad is None:                                # gradients from elsewhere: gather them
                 grad = state["flat_grad"]

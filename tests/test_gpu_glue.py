@@ -88,6 +88,27 @@ def test_flat_adam_matches_torch_adam(ops, weight_decay):
     assert opt_a.steps_applied == 6
 
 
+def test_flat_adam_survives_replaced_parameter_storage(ops):
+    """`load_state_dict(assign=True)` / `p.data = ...` after construction: the optimizer adopts the
+    new values instead of updating a stale copy."""
+    from nerf_amd.optim import Adam
+    mine, theirs, g = _param_sets(13)
+    opt_a, opt_b = Adam(mine, lr=1e-3), torch.optim.Adam(theirs, lr=1e-3)
+    for it in range(3):
+        if it == 1:
+            for p, q in zip(mine, theirs):
+                fresh = (torch.rand(p.shape, generator=g) - 0.5).cuda()
+                p.data = fresh.clone()                   # no longer a view of the flat buffer
+                q.data.copy_(fresh)
+        for p, q in zip(mine, theirs):
+            grad = (torch.rand(p.shape, generator=g) - 0.5).cuda()
+            p.grad, q.grad = grad.clone(), grad.clone()
+        opt_a.step()
+        opt_b.step()
+        for k, (p, q) in enumerate(zip(mine, theirs)):
+            assert_close(p.detach().cpu(), q.detach().cpu(), rtol=1e-5, atol=1e-6, what=f"step {it} tensor {k}")
+
+
 def test_flat_adam_behind_grad_scaler_skips_on_inf(ops):
     from nerf_amd.optim import Adam
     mine, theirs, g = _param_sets(12)
