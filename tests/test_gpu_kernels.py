@@ -485,3 +485,32 @@ def test_scripted_reference_model_renders(ops, tmp_path):
     out3 = bvr.render_volume(again, again, ro.cuda(), rd.cuda())
     ops.set_precision(None)
     assert all(torch.equal(a, b) for a, b in zip(outs[1], out3))
+
+
+def test_limits_deepest_model_and_rejected_shapes(ops):
+    """The largest supported field (width 256, depth 16) against the oracle, and clear errors for
+    shapes outside the limits (width over 256 or not a multiple of 16, unknown activation)."""
+    from nerf_amd.core import NeRF, PositionalEncoding
+    torch.manual_seed(11)
+    model = NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 6), 256, 16).cuda()
+    g = torch.Generator().manual_seed(12)
+    rx, rd = (torch.rand(70, 3, generator=g) * 2 - 1) * 3, torch.rand(70, 3, generator=g) * 2 - 1
+    f = O.positional_freq_bands(6)
+    om = O.Model({k: v.detach().cpu() for k, v in model.named_parameters()}, O.make_encoder("pe", f),
+                 O.make_encoder("pe", f), "relu", True)
+    with torch.no_grad():
+        want_s, want_c = om(rx, rd)
+        ops.set_precision("fp32")
+        got_s, got_c = model(rx.cuda(), rd.cuda())
+        ops.set_precision("bf16")
+        bf_s, bf_c = model(rx.cuda(), rd.cuda())
+        ops.set_precision(None)
+    assert_close(got_s.cpu(), want_s, rtol=1e-4, atol=1e-6, what="sigma, depth 16")
+    assert_close(got_c.cpu(), want_c, rtol=1e-4, atol=1e-5, what="rgb, depth 16")
+    assert_close(bf_c.cpu(), want_c, rtol=0, atol=1e-2, what="rgb, depth 16, bf16")
+    for bad in (lambda: NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 6), 272, 4),
+                lambda: NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 6), 40, 4),
+                lambda: NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 6), 64, 4, torch.nn.Tanh)):
+        m = bad().cuda()
+        with pytest.raises((RuntimeError, NotImplementedError)):
+            m(rx.cuda(), rd.cuda())
