@@ -244,9 +244,12 @@ __global__ __launch_bounds__(256) void segment_lengths_kernel(const float* __res
     }
 }
 
-static int composite_grid(int64_t n_rays, int n) {
+// Workgroups to launch.  Kernels that also stream the colour rows (forward with rgb, backward) keep
+// more bytes in flight per wavefront and run fastest with (nearly) one pass per wavefront; the light
+// weights-only forward is fastest with the resident set (8 workgroups per CU) looping over rays.
+static int composite_grid(int64_t n_rays, int n, bool colour_rows) {
     const int per_block = K3_WAVES * (n > 256 ? 1 : (n > 32 && n <= 64 ? 4 : 2));   // rays in flight per workgroup
-    return (int)std::min<int64_t>((n_rays + per_block - 1) / per_block, 256 * 8);
+    return (int)std::min<int64_t>((n_rays + per_block - 1) / per_block, colour_rows ? 256 * 128 : 256 * 8);
 }
 
 }  // namespace nerfx
@@ -285,7 +288,7 @@ extern "C" int nerfx_composite_fwd(const float* sigma, const float* rgb, const f
     if (n_rays == 0) return 0;
     NERFX_REQUIRE(!(rgb_map && !rgb), "rgb_map requested without rgb");
     NERFX_REQUIRE(!(depth_map && !t), "depth_map requested without t");
-    K3_DISPATCH(n, composite_fwd_kernel, dim3(composite_grid(n_rays, n)), dim3(64 * K3_WAVES), 0,
+    K3_DISPATCH(n, composite_fwd_kernel, dim3(composite_grid(n_rays, n, rgb != nullptr)), dim3(64 * K3_WAVES), 0,
                 (hipStream_t)stream, sigma, rgb, t, rd, delta, n_rays, n, weights, rgb_map, depth_map);
     return launch_status("composite_fwd_kernel");
 }
@@ -299,7 +302,7 @@ extern "C" int nerfx_composite_bwd(const float* sigma, const float* rgb, const f
     NERFX_REQUIRE(g_sigma != nullptr, "g_sigma is NULL");
     NERFX_REQUIRE(!(g_rgb_map && !rgb), "g_rgb_map given without rgb");
     NERFX_REQUIRE(!(g_depth && !t), "g_depth given without t");
-    K3_DISPATCH(n, composite_bwd_kernel, dim3(composite_grid(n_rays, n)), dim3(64 * K3_WAVES), 0,
+    K3_DISPATCH(n, composite_bwd_kernel, dim3(composite_grid(n_rays, n, true)), dim3(64 * K3_WAVES), 0,
                 (hipStream_t)stream, sigma, rgb, t, rd, delta, n_rays, n, g_rgb_map, g_depth, g_weights,
                 g_sigma, g_rgb);
     return launch_status("composite_bwd_kernel");

@@ -102,6 +102,43 @@ __global__ __launch_bounds__(256) void sample_t_kernel(const float* __restrict__
     }
 }
 
+// The same for sample counts that are multiples of four (up to 1024): a thread owns four
+// consecutive samples of one ray and keeps its sample slot while it walks over rays, so the
+// index arithmetic is one 32-bit division per thread and every store is 128 bits wide.
+__global__ __launch_bounds__(256) void sample_t4_kernel(const float* __restrict__ rd, int64_t n_rays, float tn, float tf,
+                                                        int n, const float* __restrict__ u, float* __restrict__ t_out,
+                                                        float* __restrict__ delta_out) {
+    const int tpr = n >> 2, rpb = 256 / tpr;                           // threads per ray, rays per workgroup pass
+    const int slot = (int)threadIdx.x / tpr, i0 = ((int)threadIdx.x - slot * tpr) * 4;
+    if (slot >= rpb) return;
+    float lin[5];                                                      // without jitter the row is the same for every ray
+#pragma unroll
+    for (int e = 0; e < 5; ++e) lin[e] = linspace_at(tn, tf, n, min(i0 + e, n - 1));
+    for (int64_t ray = (int64_t)blockIdx.x * rpb + slot; ray < n_rays; ray += (int64_t)gridDim.x * rpb) {
+        const int64_t q = ray * n + i0;
+        float t[5];
+        if (u) {
+            const float4 uv = *reinterpret_cast<const float4*>(u + q);
+            t[0] = stratified_at(tn, tf, n, i0, uv.x);
+            t[1] = stratified_at(tn, tf, n, i0 + 1, uv.y);
+            t[2] = stratified_at(tn, tf, n, i0 + 2, uv.z);
+            t[3] = stratified_at(tn, tf, n, i0 + 3, uv.w);
+            t[4] = i0 + 4 < n ? stratified_at(tn, tf, n, i0 + 4, u[q + 4]) : 0.0f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 5; ++e) t[e] = lin[e];
+        }
+        if (t_out) *reinterpret_cast<float4*>(t_out + q) = make_float4(t[0], t[1], t[2], t[3]);
+        if (delta_out) {                                               // ray.py:62-65
+            const float len = norm3(rd[3 * ray], rd[3 * ray + 1], rd[3 * ray + 2]);
+            float d[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = __fmul_rn(i0 + e + 1 < n ? __fsub_rn(t[e + 1], t[e]) : 1e10f, len);
+            *reinterpret_cast<float4*>(delta_out + q) = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(K1_THREADS) void encode_points_kernel(
     const float* __restrict__ v, int64_t n_points, int kind, int n, const float* __restrict__ table,
     float* __restrict__ phi) {
@@ -149,6 +186,14 @@ extern "C" int nerfx_sample_encode_fwd(const float* ro, const float* rd, int64_t
     if (phi_x) { int e = check_encoder(kx, nx, tx, "phi_x"); if (e) return e; }
     if (phi_d) { int e = check_encoder(kd, nd, td, "phi_d"); if (e) return e; }
     if (!rx && !phi_x && !phi_d) {
+        const bool aligned = (((uintptr_t)t | (uintptr_t)delta | (uintptr_t)u) & 15) == 0;
+        if (n_samples % 4 == 0 && aligned) {
+            const int rpb = 256 / (n_samples / 4);
+            const int grid4 = (int)std::min<int64_t>((n_rays + rpb - 1) / rpb, 256 * 16);
+            hipLaunchKernelGGL(sample_t4_kernel, dim3(grid4), dim3(256), 0, (hipStream_t)stream, rd, n_rays, tn, tf,
+                               n_samples, u, t, delta);
+            return launch_status("sample_t4_kernel");
+        }
         const int grid = (int)std::min<int64_t>((n_rays * n_samples + 255) / 256, 256 * 16);
         hipLaunchKernelGGL(sample_t_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rd, n_rays, tn, tf, n_samples, u,
                            t, delta);

@@ -64,7 +64,10 @@ def main():
     t = torch.sort(torch.rand(B, n, device=dev, generator=g) * 4 + 2, dim=-1).values
     s = timed(lambda: ops.composite_fwd(sigma, rgb, t, rd), it)
     report("K3 composite_fwd (N=128, colour + depth)", s, 512 + 1536 + 512 + 12 + 12 + 4 + 512, "")
-    s = timed(lambda: ops.composite_fwd(sigma[:, :64].contiguous(), None, t[:, :64].contiguous(), rd, want_depth=False), it)
+    s = timed(lambda: ops.composite_fwd(sigma, None, t, rd, want_depth=False), it)
+    report("K3 composite_fwd (N=128, weights only)", s, 512 + 512 + 12 + 512, "no colour rows: 16-byte slices only")
+    sigma64, t64 = sigma[:, :64].contiguous(), t[:, :64].contiguous()
+    s = timed(lambda: ops.composite_fwd(sigma64, None, t64, rd, want_depth=False), it)
     report("K3 composite_fwd (N=64, weights only)", s, 256 + 256 + 12 + 256, "coarse pass")
     g_map = torch.rand(B, 3, device=dev, generator=g)
     s = timed(lambda: ops.composite_bwd(sigma, rgb, t, rd, None, g_map, None, None), it)
