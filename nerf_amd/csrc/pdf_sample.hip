@@ -43,6 +43,16 @@ __device__ __forceinline__ int lower_bound(const float* a, int n, float x) {
     return lo;
 }
 
+// The workgroup is ONE wavefront, whose LDS operations complete in issue order: steps that hand
+// values between lanes through LDS only need the compiler to keep its memory operations in program
+// order (a wavefront-scope fence, which emits no instruction).  A workgroup barrier here would also
+// wait for every global access in flight, i.e. for the prefetch of the next ray and for the stores
+// of the previous one, once per ray.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // R = values of each row a lane holds: the kernel is instantiated for rows of up to 64, 128 and
 // 256 samples, so the usual 64 + 64 case carries no loops or predicates for longer rows.
 template <int R>
@@ -69,11 +79,17 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
             ur[q] = (u_g && i < nf) ? u_g[ray * nf + i] : 0.f;
         }
     };
-    if ((int64_t)blockIdx.x < n_rays) fetch(blockIdx.x, t_nxt, w_nxt, u_nxt);
-    for (int64_t ray = blockIdx.x; ray < n_rays; ray += gridDim.x) {
+    // The hand-over cur <- nxt sits in the MIDDLE of an iteration, before the output stores: the
+    // wait for the prefetched values then also covers only stores issued half an iteration
+    // earlier, which have long completed, instead of the stores issued just before the loop turns.
+    if ((int64_t)blockIdx.x < n_rays) fetch(blockIdx.x, t_cur, w_cur, u_cur);
 #pragma unroll
-        for (int q = 0; q < R; ++q) { t_cur[q] = t_nxt[q]; w_cur[q] = w_nxt[q]; u_cur[q] = u_nxt[q]; }
-        if (ray + gridDim.x < n_rays) fetch(ray + gridDim.x, t_nxt, w_nxt, u_nxt);
+    for (int q = 0; q < R; ++q) {
+        asm volatile("" : "+v"(t_cur[q]), "+v"(w_cur[q]), "+v"(u_cur[q]));       // landed before the loop starts
+        t_nxt[q] = 0.f; w_nxt[q] = 0.f; u_nxt[q] = 0.f;
+    }
+    if ((int64_t)blockIdx.x + gridDim.x < n_rays) fetch((int64_t)blockIdx.x + gridDim.x, t_nxt, w_nxt, u_nxt);
+    for (int64_t ray = blockIdx.x; ray < n_rays; ray += gridDim.x) {
         // -- pdf and cdf (ray.py:161-164, :220) --------------------------------
         float part = 0.f;
 #pragma unroll
@@ -89,7 +105,7 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
         const float total = part;
-        __syncthreads();
+        wave_sync();
         double carry = 0.0;
 #pragma unroll
         for (int q = 0; q < R; ++q) {              // cdf[k + 1] = sum_{j <= k} pdf_j
@@ -106,7 +122,7 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
             const int i = lane + 64 * q;
             if (i < nb) bins[i] = __fmul_rn(0.5f, __fadd_rn(tc[i], tc[i + 1]));
         }
-        __syncthreads();
+        wave_sync();
         if (cdf_out)
             for (int i = lane; i < nb; i += 64) cdf_out[ray * nb + i] = cdf[i];
         // -- inverse cdf (ray.py:166-186) ---------------------------------------
@@ -127,7 +143,13 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
             if (idx_out) idx_out[ray * nf + j] = idx;
             if (t_pdf_out) t_pdf_out[ray * nf + j] = t;
         }
-        __syncthreads();
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            t_cur[q] = t_nxt[q]; w_cur[q] = w_nxt[q]; u_cur[q] = u_nxt[q];
+            asm volatile("" : "+v"(t_cur[q]), "+v"(w_cur[q]), "+v"(u_cur[q]));   // the wait for the prefetch stays here
+        }
+        if (ray + 2 * (int64_t)gridDim.x < n_rays) fetch(ray + 2 * (int64_t)gridDim.x, t_nxt, w_nxt, u_nxt);
         // -- merge (ray.py:223) ---------------------------------------------------
 #pragma unroll
         for (int q = 0; q < R; ++q) {
@@ -135,7 +157,7 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
             if (j + 1 < nf && !(tp[j] <= tp[j + 1])) unsorted = 1;    // benign race: all write 1
             if (j + 1 < nc && !(tc[j] <= tc[j + 1])) unsorted = 1;
         }
-        __syncthreads();
+        wave_sync();
         const int n = nc + nf;
         float* out = t_sorted + ray * n;
         if (!unsorted) {
@@ -148,7 +170,7 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
 #pragma unroll
             for (int q = 0; q < R; ++q) hist[lane + 64 * q] = 0;
             if (lane == 0) hist[ROW] = 0;
-            __syncthreads();
+            wave_sync();
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 const int j = lane + 64 * q;
@@ -160,7 +182,7 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
                 out[j + r] = v;
                 atomicAdd(&hist[r], 1);
             }
-            __syncthreads();
+            wave_sync();
             int carry = 0;                                           // #{j : r_j <= i}: inclusive running sum of hist
 #pragma unroll
             for (int q = 0; q < R; ++q) {
@@ -183,7 +205,7 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
                 float v = i < nc ? tc[i] : (i < n ? tp[i - nc] : INFINITY);
                 srt[i] = v == v ? v : INFINITY;                          // NaNs sort last
             }
-            __syncthreads();
+            wave_sync();
             for (int k = 2; k <= p2; k <<= 1)
                 for (int j = k >> 1; j > 0; j >>= 1) {
                     for (int i = lane; i < p2; i += 64) {
@@ -194,11 +216,11 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
                             if ((a > b) == up) { srt[i] = b; srt[partner] = a; }
                         }
                     }
-                    __syncthreads();
+                    wave_sync();
                 }
             for (int i = lane; i < n; i += 64) out[i] = srt[i];
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
