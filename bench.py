@@ -12,7 +12,7 @@ frame (the 40-view orbit is frame-sharded: no collective) and rank 0 gathers rgb
 roofline: every launch of the fused MLP kernel inside the timed region is bracketed by HIP
 events on the launch stream; achieved = algorithmic FLOPs of those launches / their summed
 duration (so per-launch FLOPs / average launch duration), against the dense MFMA peak.
-cpu_baseline: the CPU oracle (oracle/nerf_oracle.py, torch CPU fp32) renders a 100x100
+cpu_baseline: the CPU oracle (oracle/nerf_oracle.py, torch CPU fp32) renders a 200x200
 frame of the same workload on this host's cores (rank 0, N = 1 only).
 """
 import argparse
@@ -50,7 +50,7 @@ def cpu_baseline(model, tn, tf, nc, nf):
     f = O.positional_freq_bands(6)
     om = O.Model(params, O.make_encoder("pe", f), O.make_encoder("pe", f), "relu", True)
     g = torch.Generator().manual_seed(0)
-    H = W = 100
+    H = W = 200
     ro, rd = torch.rand(H * W, 3, generator=g), torch.rand(H * W, 3, generator=g)
     O.infer(om, om, ro[:1000], rd[:1000], 10, 100, tn, tf, nc, nf, batch_size=16384)      # warm-up
     best = float("inf")
@@ -59,7 +59,7 @@ def cpu_baseline(model, tn, tf, nc, nf):
         O.infer(om, om, ro, rd, H, W, tn, tf, nc, nf, batch_size=16384)
         best = min(best, time.perf_counter() - t0)
     return {"value": H * W / best, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{H}x{W} frame (10,000 rays) of the same workload via oracle.infer, best of 2, "
+            "sample": f"{H}x{W} frame ({H * W:,} rays) of the same workload via oracle.infer, best of 2, "
                       f"{best:.2f} s"}
 
 
