@@ -44,7 +44,14 @@ __device__ __forceinline__ float activation_slope(float z) {
 // tiles, gets the density head's contribution (SIGMA: + w_sigma[f] * gs), is multiplied by
 // act'(z) of the rows it belongs to (ACT < 0: a plain Linear, no factor), is stored to the
 // gradient tape at tiles `tile0`.. and becomes hout.
-template <int PREC, class RG, int ACT, int NT, int CT, bool SIGMA, int HN_IN, int HN_OUT>
+//
+// Tape traffic and the hand-overs: a hand-over waits on the vector-memory counter, which retires
+// in issue order.  The z tiles of a group (bf16) are therefore requested BEFORE the group's
+// hand-over and used after its MFMA run, and the hand-over lets them, and the gradient tiles the
+// previous group has just stored, stay in flight (PREV_OPS: what the caller's previous step left).
+// Before the z tiles are used, the wait in turn leaves the pieces requested by this group's
+// hand-overs in flight.
+template <int PREC, class RG, int ACT, int NT, int CT, bool SIGMA, int PREV_OPS, int HN_IN, int HN_OUT>
 __device__ __forceinline__ void linear_bwd(WeightRing<RG>& ring, int h, const typename Prec<PREC>::Frag (&hin)[HN_IN],
                                            typename Prec<PREC>::Frag (&hout)[HN_OUT], const Tape<PREC>& ztape,
                                            const Tape<PREC>& gtape, int tile0, lds_floats_t sigw, float gs) {
@@ -54,9 +61,16 @@ __device__ __forceinline__ void linear_bwd(WeightRing<RG>& ring, int h, const ty
     constexpr int KB_PER_PIECE = PIECE_UNITS / NG;
     constexpr int CHAIN_KU = CT * P::UPT;
     constexpr int CHAIN_PIECES = pad_to_piece(CHAIN_KU * NG) / PIECE_UNITS;
+    constexpr bool PREFETCH = ACT >= 0 && PREC == NERFX_PREC_BF16;
+    constexpr int Z_OPS = PREFETCH ? NG * Tape<PREC>::TILE_VMEM_OPS : 0;
     static_assert(CHAIN_KU <= HN_IN && NT * P::UPT <= HN_OUT, "fragment arrays too small");
+    auto group = [&](int grp, auto stored_before) {
+        constexpr int YOUNGER = decltype(stored_before)::value + Z_OPS;
+        typename Tape<NERFX_PREC_BF16>::Raw zraw[NG];
+        if constexpr (PREFETCH) {
 #pragma unroll
-    for (int grp = 0; grp < NT / NG; ++grp) {
+            for (int t = 0; t < NG; ++t) zraw[t] = ztape.load_raw_async(tile0 + grp * NG + t, h);
+        }
         f32x16 acc[NG];
 #pragma unroll
         for (int t = 0; t < NG; ++t)
@@ -68,16 +82,22 @@ __device__ __forceinline__ void linear_bwd(WeightRing<RG>& ring, int h, const ty
             const int ku0 = p0 * KB_PER_PIECE;
             if (CHAIN_PIECES - p0 >= SYNC_PIECES) {
                 constexpr int KU = SYNC_PIECES * KB_PER_PIECE;
-                ring.template acquire<SYNC_PIECES>();
+                if (p0 == 0) ring.template acquire<SYNC_PIECES, YOUNGER>();
+                else ring.template acquire<SYNC_PIECES>();
                 run_units<PREC, RG, NG, KU * NG>(ring, acc, [&](int k) { return hin[ku0 + k]; });
                 ring.template release<SYNC_PIECES>();
             } else {
                 constexpr int KU = CHAIN_KU - (CHAIN_PIECES - TAIL) * KB_PER_PIECE;
-                ring.template acquire<TAIL>();
+                if (p0 == 0) ring.template acquire<TAIL, YOUNGER>();
+                else ring.template acquire<TAIL>();
                 run_units<PREC, RG, NG, (KU > 0 ? KU : 1) * NG>(ring, acc, [&](int k) { return hin[ku0 + k]; });
                 ring.template release<TAIL>();
             }
         }
+        // the z tiles were requested before this group's hand-overs, which have issued CHAIN_PIECES
+        // pieces since: everything older than those transfers has arrived after this wait
+        if constexpr (PREFETCH)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CHAIN_PIECES * WeightRing<RG>::LPW) : "memory");
 #pragma unroll
         for (int t = 0; t < NG; ++t) {
             const int tile = grp * NG + t;
@@ -90,7 +110,9 @@ __device__ __forceinline__ void linear_bwd(WeightRing<RG>& ring, int h, const ty
                 }
             }
             if (ACT >= 0) {
-                const f32x16 z = ztape.load_tile(tile0 + tile, h);
+                f32x16 z;
+                if constexpr (PREFETCH) z = Tape<NERFX_PREC_BF16>::expand(zraw[t]);
+                else z = ztape.load_tile(tile0 + tile, h);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] *= activation_slope<PREC, ACT>(z[r]);
             }
@@ -98,8 +120,16 @@ __device__ __forceinline__ void linear_bwd(WeightRing<RG>& ring, int h, const ty
 #pragma unroll
             for (int s = 0; s < P::UPT; ++s) hout[tile * P::UPT + s] = P::from_acc(acc[t], s);
         }
-    }
+    };
+    // every group stores NG gradient tiles after its run: at least NG * TILE_VMEM_OPS instructions
+    group(0, std::integral_constant<int, PREV_OPS>{});
+#pragma unroll
+    for (int grp = 1; grp < NT / NG; ++grp) group(grp, std::integral_constant<int, NG * Tape<PREC>::TILE_VMEM_OPS>{});
 }
+
+// Store instructions the last group of a linear_bwd with NT output tiles leaves behind (a lower bound).
+template <int PREC>
+__host__ __device__ constexpr int stores_left(int nt) { return group_tiles(PREC, nt) * Tape<PREC>::TILE_VMEM_OPS; }
 
 template <int PREC, int WT, class RG, int ACT>
 __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) void mlp_bwd_kernel(const BwdArgs a) {
@@ -149,18 +179,19 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         Frag A[HN], B[HN];
 #pragma unroll
         for (int s = 0; s < P::UPT; ++s) A[s] = P::from_acc(top, s);
-        linear_bwd<PREC, RG, ACT, RT, 1, false>(ring, h, A, B, zt, gt, a.z_tile[feat + 1], sigw, gs);   // -> rgb.0
-        linear_bwd<PREC, RG, -1, WT, RT, false>(ring, h, B, A, zt, gt, a.z_tile[feat], sigw, gs);       // -> features
-        linear_bwd<PREC, RG, ACT, WT, WT, true>(ring, h, A, B, zt, gt, a.z_tile[feat - 1], sigw, gs);   // -> last trunk layer
+        constexpr int S_RT = stores_left<PREC>(RT), S_WT = stores_left<PREC>(WT);
+        linear_bwd<PREC, RG, ACT, RT, 1, false, 0>(ring, h, A, B, zt, gt, a.z_tile[feat + 1], sigw, gs);      // -> rgb.0
+        linear_bwd<PREC, RG, -1, WT, RT, false, S_RT>(ring, h, B, A, zt, gt, a.z_tile[feat], sigw, gs);      // -> features
+        linear_bwd<PREC, RG, ACT, WT, WT, true, S_WT>(ring, h, A, B, zt, gt, a.z_tile[feat - 1], sigw, gs);  // -> last trunk layer
         // trunk layers feat-1 .. 1, each producing the gradient of the layer below it
         int li = feat - 1;
         if (li >= 1) {
-            linear_bwd<PREC, RG, ACT, WT, WT, false>(ring, h, B, A, zt, gt, a.z_tile[li - 1], sigw, gs);
+            linear_bwd<PREC, RG, ACT, WT, WT, false, S_WT>(ring, h, B, A, zt, gt, a.z_tile[li - 1], sigw, gs);
             --li;
         }
         for (; li >= 2; li -= 2) {
-            linear_bwd<PREC, RG, ACT, WT, WT, false>(ring, h, A, B, zt, gt, a.z_tile[li - 1], sigw, gs);
-            linear_bwd<PREC, RG, ACT, WT, WT, false>(ring, h, B, A, zt, gt, a.z_tile[li - 2], sigw, gs);
+            linear_bwd<PREC, RG, ACT, WT, WT, false, S_WT>(ring, h, A, B, zt, gt, a.z_tile[li - 1], sigw, gs);
+            linear_bwd<PREC, RG, ACT, WT, WT, false, S_WT>(ring, h, B, A, zt, gt, a.z_tile[li - 2], sigw, gs);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -110,6 +110,36 @@ struct Tape {
             for (int q = 0; q < 4; ++q) reinterpret_cast<f32x4*>(p)[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
         }
     }
+    // 16-byte accesses per lane and tile: the fewest instructions a tile's load or store can take
+    static constexpr int TILE_VMEM_OPS = BF16 ? 2 : 4;
+    // A bf16 tile as loaded, for loads that are issued long before their values are needed.
+    // hipcc drains the whole vector-memory counter at the first use of an ordinary load's result
+    // while LDS-DMA transfers are in flight, so these two loads are issued from asm, which the
+    // compiler does not track: the CALLER waits (s_waitcnt vmcnt(n), n = vector-memory
+    // instructions it has issued since) before it hands the tile to expand().
+    struct Raw { u32x4 w[2]; };
+    __device__ __forceinline__ Raw load_raw_async(int tile, int h) const {
+        static_assert(BF16, "raw tiles are the bf16 form");
+        const T* p = at(tile, 16 * h);
+        Raw r;
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                     : "=&v"(r.w[0]), "=&v"(r.w[1]) : "v"(p) : "memory");
+        return r;
+    }
+    // The values of a raw tile.  The empty asm pins the registers: nothing derived from them is
+    // computed before this point.
+    static __device__ __forceinline__ f32x16 expand(Raw r) {
+        asm volatile("" : "+v"(r.w[0]), "+v"(r.w[1]));
+        f32x16 v;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[8 * q + 2 * e] = __builtin_bit_cast(float, r.w[q][e] << 16);
+                v[8 * q + 2 * e + 1] = __builtin_bit_cast(float, r.w[q][e] & 0xFFFF0000u);
+            }
+        return v;
+    }
     __device__ __forceinline__ f32x16 load_tile(int tile, int h) const {
         const T* p = at(tile, 16 * h);
         f32x16 v;
@@ -182,10 +212,15 @@ struct WeightRing {
     // (RING_AHEAD - N) newest pieces has landed), meet the other waves -- their shares have
     // landed too and nobody reads anything older any more -- then refill the N slots that
     // fell out of the window.
-    template <int N>
+    // YOUNGER: vector-memory instructions (tape loads and stores) this wave has issued since its
+    // last issue() and which may stay in flight across the hand-over.  The counter retires in issue
+    // order, so the newest (RING_AHEAD - N) pieces plus those YOUNGER instructions may remain.  It
+    // must not exceed the true number (a lower bound is safe: the wait only gets stricter).
+    template <int N, int YOUNGER = 0>
     __device__ __forceinline__ void acquire() {
         static_assert(N >= 1 && N <= SYNC_PIECES, "hand-over larger than the ring's slack");
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING_AHEAD - N) * LPW) : "memory");
+        static_assert(YOUNGER >= 0 && (RING_AHEAD - N) * LPW + YOUNGER <= 63, "vmcnt is a 6-bit field");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING_AHEAD - N) * LPW + YOUNGER) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
