@@ -221,6 +221,16 @@ struct WeightRing {
         static_assert(N >= 1 && N <= SYNC_PIECES, "hand-over larger than the ring's slack");
         static_assert(YOUNGER >= 0 && (RING_AHEAD - N) * LPW + YOUNGER <= 63, "vmcnt is a 6-bit field");
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING_AHEAD - N) * LPW + YOUNGER) : "memory");
+        arrive<N>();
+    }
+    // The hand-over without its wait, for callers that pick the wait themselves (wait_for<N, YOUNGER>).
+    template <int N, int YOUNGER>
+    static __device__ __forceinline__ void wait_for() {
+        static_assert(YOUNGER >= 0 && (RING_AHEAD - N) * LPW + YOUNGER <= 63, "vmcnt is a 6-bit field");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING_AHEAD - N) * LPW + YOUNGER) : "memory");
+    }
+    template <int N>
+    __device__ __forceinline__ void arrive() {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -435,8 +445,10 @@ constexpr bool uses_stash() { return PREC == NERFX_PREC_BF16 && !BIGENC && WT >=
 //   raw  : if non-null (NT == 1 only) receives the fp32 accumulator tile instead of hout
 //   ztape: training forward (TRAIN): the pre-activation output goes to tape tiles ztile..;
 //          with an encoder segment, its B operands go to tiles etile.. in slot order
+//   PREV_OPS (TRAIN): tape stores the caller's previous step has left in flight (a lower bound);
+//          the first hand-over of a group lets them, or the previous group's, stay in flight
 template <int PREC, class RG, int ACT, bool BIGENC, int NT, int CT, bool SIGMA, bool STASH = false, bool TRAIN = false,
-          int HN_IN = 0, int HN_OUT = 0>
+          int PREV_OPS = 0, int HN_IN = 0, int HN_OUT = 0>
 __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias, int h,
                                         const typename Prec<PREC>::Frag (&hin)[HN_IN],
                                         typename Prec<PREC>::Frag (&hout)[HN_OUT],
@@ -451,6 +463,7 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
     constexpr int CHAIN_PIECES = pad_to_piece(CHAIN_KU * NG) / PIECE_UNITS;
     constexpr int ENC_PIECES = pad_to_piece(ENC_BLOCK * NG) / PIECE_UNITS;   // per ENC_BLOCK k-units
     static_assert(CHAIN_KU <= HN_IN && NT * P::UPT <= HN_OUT, "fragment arrays too small");
+    constexpr int STORED = TRAIN ? NG * Tape<PREC>::TILE_VMEM_OPS : 0;   // tape stores of one group, at least
     float dot = 0.0f;
 #pragma unroll
     for (int grp = 0; grp < NT / NG; ++grp) {
@@ -468,7 +481,13 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
         if (with_enc) {
             if (!BIGENC) {                                         // register-resident encoding
                 st.mark(ST_EPILOGUE);
-                ring.template acquire<ENC_PIECES>();
+                if constexpr (TRAIN) {
+                    if (grp == 0) ring.template wait_for<ENC_PIECES, PREV_OPS>();
+                    else ring.template wait_for<ENC_PIECES, STORED>();
+                    ring.template arrive<ENC_PIECES>();
+                } else {
+                    ring.template acquire<ENC_PIECES>();
+                }
                 st.mark(ST_ACQUIRE);
                 if constexpr (STASH) {                             // B operands from the wave's LDS stash
                     static_assert(PREC == NERFX_PREC_BF16 && NG == 2, "stash blocks exist for bf16, two tiles");
@@ -507,7 +526,13 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
             if (CHAIN_PIECES - p0 >= SYNC_PIECES) {
                 constexpr int KU = SYNC_PIECES * KB_PER_PIECE;
                 st.mark(ST_EPILOGUE);
-                ring.template acquire<SYNC_PIECES>();
+                if constexpr (TRAIN) {                             // the group's first hand-over lets tape stores fly
+                    if (p0 == 0 && !with_enc) ring.template wait_for<SYNC_PIECES, (PREV_OPS < STORED ? PREV_OPS : STORED)>();
+                    else ring.template wait_for<SYNC_PIECES, 0>();
+                    ring.template arrive<SYNC_PIECES>();
+                } else {
+                    ring.template acquire<SYNC_PIECES>();
+                }
                 st.mark(ST_ACQUIRE);
                 run_units<PREC, RG, NG, KU * NG>(ring, acc, [&](int k) { return hin[ku0 + k]; });
                 st.mark(ST_RUN);
@@ -515,7 +540,13 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
             } else {
                 constexpr int KU = CHAIN_KU - (CHAIN_PIECES - TAIL) * KB_PER_PIECE;   // k-units in the tail run
                 st.mark(ST_EPILOGUE);
-                ring.template acquire<TAIL>();
+                if constexpr (TRAIN) {                             // the group's first hand-over lets tape stores fly
+                    if (p0 == 0 && !with_enc) ring.template wait_for<TAIL, (PREV_OPS < STORED ? PREV_OPS : STORED)>();
+                    else ring.template wait_for<TAIL, 0>();
+                    ring.template arrive<TAIL>();
+                } else {
+                    ring.template acquire<TAIL>();
+                }
                 st.mark(ST_ACQUIRE);
                 run_units<PREC, RG, NG, (KU > 0 ? KU : 1) * NG>(ring, acc, [&](int k) { return hin[ku0 + k]; });
                 st.mark(ST_RUN);
@@ -638,6 +669,8 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         st.mark(ST_ENCODE);
         Frag A[HN], B[HN];                                        // ping-pong activation fragments
         float dot = 0.0f;
+        // tape stores a full-width layer's last group leaves in flight for the next layer's first hand-over
+        constexpr int S_WT = TRAIN ? group_tiles(PREC, WT) * Tape<PREC>::TILE_VMEM_OPS : 0;
         // ---- fc_1 then fc_2; fc_2's first layer optionally sees [phi_x | h] (model.py:71-73).
         // Layer 0 writes A; the remaining 2 hd - 1 trunk layers alternate A -> B, B -> A, so the
         // last one always lands in B.
@@ -655,13 +688,13 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
 #pragma unroll
         for (; li + 1 <= last; li += 2) {
             refresh(li);
-            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN>(ring, cst + li * BIAS_STRIDE, h, A, B, li == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[li]);
+            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN, S_WT>(ring, cst + li * BIAS_STRIDE, h, A, B, li == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[li]);
             refresh(li + 1);
-            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN>(ring, cst + (li + 1) * BIAS_STRIDE, h, B, A, li + 1 == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[li + 1]);
+            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN, S_WT>(ring, cst + (li + 1) * BIAS_STRIDE, h, B, A, li + 1 == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[li + 1]);
         }
         if (last > 0) {
             refresh(last);
-            dot = linear<PREC, RG, ACT, BIGENC, WT, WT, true, STASH, TRAIN>(ring, cst + last * BIAS_STRIDE, h, A, B, last == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[last]);
+            dot = linear<PREC, RG, ACT, BIGENC, WT, WT, true, STASH, TRAIN, S_WT>(ring, cst + last * BIAS_STRIDE, h, A, B, last == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[last]);
         }
         // ---- density head (model.py:75, activations.py:33-35) ------------------------------
         st.mark(ST_EPILOGUE);
@@ -676,7 +709,7 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         if (colour) {
             li = last + 1;
             // ---- features: Linear without activation (model.py:51, :76): B -> A ------------
-            linear<PREC, RG, -1, BIGENC, WT, WT, false, false, TRAIN>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li]);
+            linear<PREC, RG, -1, BIGENC, WT, WT, false, false, TRAIN, S_WT>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li]);
             ++li;
             // ---- rgb.0 on [phi_d | features] (model.py:53, :76): A -> B ---------------------
             { st.mark(ST_EPILOGUE); enc.template prepare<BIGENC>(a.ed_kind, a.ed_units, cst + a.tabd_off, h, dx, dy, dz); st.mark(ST_ENCODE); }
@@ -685,7 +718,7 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
                 for (int u = 0; u < ENC_BLOCK; ++u)
                     if (u < a.ed_units) tape.store_enc(a.tape_ed_tile, u, h, enc.cached[u]);
             }
-            linear<PREC, RG, ACT, BIGENC, RT, WT, false, false, TRAIN>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li], a.tape_ed_tile);
+            linear<PREC, RG, ACT, BIGENC, RT, WT, false, false, TRAIN, S_WT>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li], a.tape_ed_tile);
             ++li;
             // ---- rgb.2 + widened sigmoid (model.py:54, activations.py:18-20) ----------------
             f32x16 out;
