@@ -29,7 +29,9 @@ struct RingGeometry {
 // bf16: one 8-wave workgroup per CU (two waves per SIMD, 256 registers each).  A ring of 8
 // pieces (a power of two: slot arithmetic is a mask) with 4 in flight measured 2 % faster than
 // 12 with 8 in flight: the kernel is bound by instructions issued per wavefront, and the scalar
-// bookkeeping of the ring is a visible part of them.  fp32: one 4-wave workgroup per CU (512
+// bookkeeping of the ring is a visible part of them.  6 in flight with hand-overs of 2 pieces
+// (twice as many barriers, 1.5 x the time for a piece to land) measured 1 % slower for rendering
+// and 11 % slower for a training step.  fp32: one 4-wave workgroup per CU (512
 // registers).
 using RingBf16 = RingGeometry<8, 8, 4, 1>;
 using RingFp32 = RingGeometry<4, 16, 12, 1>;
