@@ -91,6 +91,11 @@ __host__ __device__ constexpr int group_tiles(int prec, int n_tiles) {
     const int cap = prec == NERFX_PREC_BF16 ? 2 : 4;
     return n_tiles < cap ? n_tiles : cap;
 }
+// Whether the training tape of this precision / activation carries sign words (Tape::signs):
+// bf16 with an activation whose slope depends on the sign of z only.
+__host__ __device__ constexpr bool tape_has_signs(int prec, int act) {
+    return prec == NERFX_PREC_BF16 && (act == NERFX_ACT_RELU || act == NERFX_ACT_LEAKY_RELU);
+}
 __host__ __device__ constexpr int pad_to_piece(int units) {
     return (units + PIECE_UNITS - 1) / PIECE_UNITS * PIECE_UNITS;
 }

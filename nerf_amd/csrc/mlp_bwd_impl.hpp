@@ -18,6 +18,7 @@ struct BwdArgs {
     const char* stream;          // packed backward units
     const float* consts;         // const block (global): the density head's weights are used
     const void* ztape;           // pre-activations (training forward)
+    const void* stape;           // their sign words (bf16, ReLU-like activations), else NULL
     void* gtape;                 // receives the pre-activation gradients
     uint64_t m_pad;              // samples per tape tile
     const float* g_sigma;        // (M)
@@ -62,12 +63,18 @@ __device__ __forceinline__ void linear_bwd(WeightRing<RG>& ring, int h, const ty
     constexpr int CHAIN_KU = CT * P::UPT;
     constexpr int CHAIN_PIECES = pad_to_piece(CHAIN_KU * NG) / PIECE_UNITS;
     constexpr bool PREFETCH = ACT >= 0 && PREC == NERFX_PREC_BF16;
-    constexpr int Z_OPS = PREFETCH ? NG * Tape<PREC>::TILE_VMEM_OPS : 0;
+    constexpr bool SIGNS = ACT >= 0 && tape_has_signs(PREC, ACT);     // one 2-byte load per tile instead of the tile
+    constexpr int Z_OPS = PREFETCH ? NG * (SIGNS ? 1 : Tape<PREC>::TILE_VMEM_OPS) : 0;
     static_assert(CHAIN_KU <= HN_IN && NT * P::UPT <= HN_OUT, "fragment arrays too small");
     auto group = [&](int grp, auto stored_before) {
         constexpr int YOUNGER = decltype(stored_before)::value + Z_OPS;
         typename Tape<NERFX_PREC_BF16>::Raw zraw[NG];
-        if constexpr (PREFETCH) {
+        uint32_t zsign[NG];
+        if constexpr (SIGNS) {
+#pragma unroll
+            for (int t = 0; t < NG; ++t)                                // untracked by the compiler, like load_raw_async
+                asm volatile("global_load_ushort %0, %1, off" : "=&v"(zsign[t]) : "v"(ztape.sign_at(tile0 + grp * NG + t, h)) : "memory");
+        } else if constexpr (PREFETCH) {
 #pragma unroll
             for (int t = 0; t < NG; ++t) zraw[t] = ztape.load_raw_async(tile0 + grp * NG + t, h);
         }
@@ -109,7 +116,19 @@ __device__ __forceinline__ void linear_bwd(WeightRing<RG>& ring, int h, const ty
                     for (int i = 0; i < 4; ++i) acc[t][4 * g + i] = fmaf(w[i], gs, acc[t][4 * g + i]);
                 }
             }
-            if (ACT >= 0) {
+            if constexpr (SIGNS) {
+                uint32_t w = zsign[t];
+                asm volatile("" : "+v"(w));                            // nothing derived from it before the wait above
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int32_t neg = __builtin_amdgcn_sbfe((int32_t)w, 15 - r, 1);   // -1 where z < 0 (or -0)
+                    if (ACT == NERFX_ACT_RELU) {
+                        const float g = acc[t][r];                     // (a temporary: see Tape::sign_word)
+                        acc[t][r] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, g) & ~(uint32_t)neg);
+                    } else
+                        acc[t][r] *= neg ? 0.01f : 1.0f;
+                }
+            } else if (ACT >= 0) {
                 f32x16 z;
                 if constexpr (PREFETCH) z = Tape<NERFX_PREC_BF16>::expand(zraw[t]);
                 else z = ztape.load_tile(tile0 + tile, h);
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
             }
             gs = a.g_sigma[m] * -expm1f(-a.sigma[m]);
         }
-        const Tape<PREC> zt{(typename Tape<PREC>::T*)a.ztape, a.m_pad, m};
+        const Tape<PREC> zt{(typename Tape<PREC>::T*)a.ztape, a.m_pad, m, (uint16_t*)a.stape};
         const Tape<PREC> gt{(typename Tape<PREC>::T*)a.gtape, a.m_pad, m};
         if (h == 0) {                                               // heads tile: positions 0..2 and 3
             using TT = typename Tape<PREC>::T;

@@ -27,7 +27,8 @@ static unsigned long long* g_stamps = nullptr;
 extern "C" void nerfx_debug_set_stamps(unsigned long long* device_buffer) { g_stamps = device_buffer; }
 
 static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0, const float* p1, const float* t,
-                      int64_t n_points, int n_samples, float* sigma, float* rgb, void* stream, void* tape = nullptr) {
+                      int64_t n_points, int n_samples, float* sigma, float* rgb, void* stream, void* tape = nullptr,
+                      void* tape_signs = nullptr) {
     NERFX_REQUIRE(model != nullptr, "model is NULL");
     NERFX_REQUIRE(precision == NERFX_PREC_FP32 || precision == NERFX_PREC_BF16, "unknown precision %d", precision);
     NERFX_REQUIRE(n_points >= 0 && n_points < (int64_t)1 << 31, "n_points %lld out of range [0, 2^31)", (long long)n_points);
@@ -52,6 +53,7 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
     if (tape) {                                                     // training forward: record the tape
         NERFX_REQUIRE(rgb != nullptr, "the training forward needs the colour output");
         a.tape = tape;
+        a.tape_signs = tape_signs;
         a.tape_m_pad = tape_m_pad(n_points);
         a.n_blocks = (uint32_t)(a.tape_m_pad / (32 * waves));       // pad columns are written too
         a.tape_ex_tile = p.tape_ex_tile; a.tape_ed_tile = p.tape_ed_tile;
@@ -89,6 +91,7 @@ extern "C" int nerfx_mlp_fwd_rays(const nerfx_model_t* model, int precision, con
 namespace {
 struct TrainWorkspace {
     char *ztape, *gtape;
+    char* stape;                 // sign words of the z tape (bf16 with ReLU-like activations), else NULL
     float* partial;
     uint64_t m_pad;
     int64_t bytes;
@@ -101,6 +104,7 @@ TrainWorkspace carve_train(const nerfx_model_t* model, int precision, int64_t n_
     char* c = (char*)base;
     w.ztape = c; c += tape_bytes;
     w.gtape = c; c += tape_bytes;
+    if (tape_has_signs(precision, p.desc.activ)) { w.stape = c; c += (int64_t)p.tape_tiles * (int64_t)w.m_pad * 4; }
     w.partial = (float*)c; c += wgrad_partial_bytes(model, precision, w.m_pad);
     w.bytes = c - (char*)base;
     return w;
@@ -123,7 +127,7 @@ static int train_fwd(const nerfx_model_t* model, int precision, const float* p0,
                   "training workspace too small: %lld < %lld bytes", (long long)workspace_bytes,
                   (long long)nerfx_mlp_train_workspace_bytes(model, precision, n_points));
     const TrainWorkspace w = carve_train(model, precision, n_points, workspace);
-    return mlp_launch(model, precision, p0, p1, t, n_points, n_samples, sigma, rgb, stream, w.ztape);
+    return mlp_launch(model, precision, p0, p1, t, n_points, n_samples, sigma, rgb, stream, w.ztape, w.stape);
 }
 
 extern "C" int nerfx_mlp_fwd_train_points(const nerfx_model_t* model, int precision, const float* x, const float* d,
@@ -157,6 +161,7 @@ extern "C" int nerfx_mlp_bwd(const nerfx_model_t* model, int precision, int64_t 
     a.stream = (const char*)model->stream_bwd_dev[precision];
     a.consts = model->const_dev;
     a.ztape = w.ztape; a.gtape = w.gtape; a.m_pad = w.m_pad;
+    a.stape = w.stape;
     a.g_sigma = g_sigma; a.g_rgb = g_rgb; a.sigma = sigma; a.rgb = rgb;
     a.n_points = (uint32_t)n_points;
     a.n_blocks = (uint32_t)(w.m_pad / (32 * waves));

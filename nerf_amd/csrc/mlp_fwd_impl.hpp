@@ -54,6 +54,7 @@ struct MlpArgs {
     int sigw_off, sigb_off, tabx_off, tabd_off, const_floats;
     unsigned long long* stamps;  // diagnostic builds: 6 cycle buckets, else NULL
     void* tape;                  // training forward: the tape to record (see Tape), else NULL
+    void* tape_signs;            // bf16 training forward: the sign words of the tape (see Tape::signs)
     uint64_t tape_m_pad;         // samples per tape tile
     int tape_ex_tile, tape_ed_tile, tape_z_tile[MAX_LAYERS];   // first tile of each encoder / layer
 };
@@ -97,6 +98,20 @@ struct Tape {
     T* base;
     uint64_t m_pad;
     uint32_t m;                  // this lane's sample
+    // bf16 training with ReLU-like activations: beside every z tile, one 16-bit word per sample
+    // and lane half holding the signs of its 16 values (bit 15 - r = sign bit of register r).  The
+    // backward chain needs nothing else of z, so it reads 2 bytes where the tile has 32.
+    uint16_t* signs = nullptr;
+    __device__ __forceinline__ uint16_t* sign_at(int tile, int h) const { return signs + ((uint64_t)tile * m_pad + m) * 2 + h; }
+    static __device__ __forceinline__ uint32_t sign_word(const f32x16& v) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = v[r];          // (bit_cast of a vector-element lvalue reads element 0 with this hipcc)
+            bits = __builtin_amdgcn_alignbit(bits, __builtin_bit_cast(uint32_t, e), 31);
+        }
+        return bits & 0xFFFFu;
+    }
     __device__ __forceinline__ T* at(int tile, int pos) const { return base + ((uint64_t)tile * m_pad + m) * 32 + pos; }
     // (callers make sure `v` does not come straight out of an MFMA: the bf16 form converts in asm)
     __device__ __forceinline__ void store_tile(int tile, int h, const f32x16& v) const {
@@ -556,6 +571,11 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
         if constexpr (TRAIN) {
 #pragma unroll
             for (int t = 0; t < NG; ++t) ztape->store_tile(ztile + grp * NG + t, h, acc[t]);
+            if constexpr (tape_has_signs(PREC, ACT)) {
+#pragma unroll
+                for (int t = 0; t < NG; ++t)
+                    *ztape->sign_at(ztile + grp * NG + t, h) = (uint16_t)Tape<PREC>::sign_word(acc[t]);
+            }
         }
         // epilogue: activation, density dot, conversion to the next layer's operands
         constexpr bool packed_relu = ACT == NERFX_ACT_RELU && P::PACKED_RELU && !SIGMA;
@@ -651,7 +671,7 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         // in registers, (re)built right before each consuming layer.
         Encoding<PREC> enc;
         enc.template prepare<BIGENC>(a.ex_kind, a.ex_units, cst + a.tabx_off, h, px, py, pz);
-        Tape<PREC> tape{(typename Tape<PREC>::T*)a.tape, a.tape_m_pad, m};   // m < m_pad also for tail lanes
+        Tape<PREC> tape{(typename Tape<PREC>::T*)a.tape, a.tape_m_pad, m, (uint16_t*)a.tape_signs};   // m < m_pad also for tail lanes
         const Tape<PREC>* zt = TRAIN ? &tape : nullptr;
         if constexpr (TRAIN && !BIGENC) {                           // wide encoders are recorded where they are evaluated
 #pragma unroll

@@ -34,7 +34,7 @@ def main():
         if "#ASMEND" in t:
             in_asm = False
             continue
-        if in_asm and t.startswith("global_load_dwordx4"):
+        if in_asm and t.startswith(("global_load_dwordx4", "global_load_ushort")):
             dst = regs(t.split(",")[0])
             pending.append({"dst": dst, "waits": 0, "line": no})
             n_loads += 1
