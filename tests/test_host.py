@@ -198,3 +198,25 @@ def test_reptile_meta_objects_reset():
     holder.update()
     assert all(torch.equal(a, b) for a, b in zip(nerf.parameters(), meta_nerf.parameters()))
     assert len(meta_optim.state_dict()["state"]) == 0
+
+
+def test_async_tape_loads_keep_their_registers(tmp_path):
+    """The bf16 backward chain issues its tape loads from inline asm, which the compiler does not
+    track: in the compiled assembly nothing may touch their destination registers before the
+    counted wait that precedes their use (tools/check_async_loads.py)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    src = os.path.join(root, "nerf_amd", "csrc", "mlp_bwd_bf16.hip")
+    asm = str(tmp_path / "mlp_bwd_bf16.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17",
+                    "-I", os.path.join(root, "include"), src, "-o", asm], check=True, capture_output=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_async_loads.py"), asm, "mlp_bwd_kernel"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-2000:]
+    checked = int(out.stdout.strip().splitlines()[-1].split()[0])
+    assert checked > 0, "the checker found no async loads: has the kernel changed?"
