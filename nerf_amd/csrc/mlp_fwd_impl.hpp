@@ -416,11 +416,15 @@ __device__ __forceinline__ void run_units(const WeightRing<RG>& ring, f32x16 (&a
         uint32_t p[N / PIECE_UNITS];
 #pragma unroll
         for (int k = 0; k < N / PIECE_UNITS; ++k) p[k] = (uint32_t)(uintptr_t)ring.unit_ptr(k * PIECE_UNITS);
+        // the wave inside a hand-scheduled run goes first on its SIMD: the other wave's epilogue fills
+        // the slots between the MFMAs instead of delaying them (render: -0.5 %; priority 2 or 3 alike)
+        __builtin_amdgcn_s_setprio(3);
         if constexpr (N == 8) run8_bf16_ng2(acc[0], acc[1], p[0], b(0), b(1), b(2), b(3));
         if constexpr (N == 16) run16_bf16_ng2(acc[0], acc[1], p[0], p[1], b(0), b(1), b(2), b(3), b(4), b(5), b(6), b(7));
         if constexpr (N == 32)
             run32_bf16_ng2(acc[0], acc[1], p[0], p[1], p[2], p[3], b(0), b(1), b(2), b(3), b(4), b(5), b(6), b(7),
                            b(8), b(9), b(10), b(11), b(12), b(13), b(14), b(15));
+        __builtin_amdgcn_s_setprio(0);
         return;
     }
     __builtin_amdgcn_sched_barrier(0);
