@@ -235,7 +235,8 @@ int nerfx_frame_finish(const float* depth, const float* rgb, int64_t n_pixels,
 /* ---- around the render in a training step (the caller `step`, train.py:72-99) -------------
  * A batch of rays out of device-resident arrays: item k = (C, ro, rd)[perm[begin + k]]
  * (perm == NULL: item begin + k), what the reference's DataLoader collates from
- * BlenderDataset.__getitem__ (blender.py:224-235; data/utils.py:26-32).  Arrays are (n_total, 3). */
+ * BlenderDataset.__getitem__ (blender.py:224-235; data/utils.py:26-32).  Arrays are (n_total, 3),
+ * perm holds n_total entries; begin + n <= n_total is required with or without perm. */
 int nerfx_gather_rays(const float* C, const float* ro, const float* rd, const int64_t* perm,
                       int64_t begin, int64_t n, int64_t n_total,
                       float* C_out, float* ro_out, float* rd_out, void* stream);

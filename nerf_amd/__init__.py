@@ -15,7 +15,7 @@ __version__ = "0.1.0"
 def install_as(name: str = "nerf") -> None:
     """Alias this package (and its submodules) under another top-level name, so
     that code written as `from nerf.core import ...` picks up the HIP path."""
-    from . import core, data, distill, infer, reptile, train, utils  # noqa: F401
+    from . import core, data, distill, infer, train, utils  # noqa: F401
     from .data import path as _data_path, utils as _data_utils  # noqa: F401
     prefix = __name__ + "."
     for mod_name, mod in list(_sys.modules.items()):

@@ -19,6 +19,10 @@ class BoundedVolumeRaymarcher:
     def __init__(self, tn: float, tf: float, samples_c: int = 64, samples_f: int = 64) -> None:
         assert tf > tn, "[NeRF] `tf` should always be > `tn`"
         assert samples_c > 0, "[NeRF] `samples_c` should always be > 0"
+        # limits of the HIP kernels (the reference has none): one wavefront handles a ray
+        if not (samples_c <= 256 and samples_f <= 256 and (samples_f <= 0 or samples_c >= 3)):
+            raise ValueError("[NeRF] the HIP kernels take samples_c <= 256, samples_f <= 256 and, with fine "
+                             f"samples, samples_c >= 3 (got {samples_c} + {samples_f})")
         self.tn, self.tf = tn, tf
         self.samples_c, self.samples_f = samples_c, samples_f
         self.samples = samples_c + samples_f
@@ -33,7 +37,10 @@ class BoundedVolumeRaymarcher:
         With `train`, gradients reach the parameters of `fine` through the fine
         pass only (the coarse pass and the sample positions carry none), and the
         requires_grad flags of both modules are toggled exactly as in
-        reference renderer.py:133,137."""
+        reference renderer.py:133,137.  Without `train` no graph is recorded, whatever
+        autograd's state: every caller in the reference renders that way under
+        inference_mode / no_grad (infer.py:13, train.py:71 for the val and test splits,
+        bench.py:149); a caller that wants gradients passes train=True."""
         B, nc, nf = ro.size(0), self.samples_c, self.samples_f
         u_c = torch.rand((B, nc), device=ro.device) if perturb else None
         u_f = torch.rand((B, nf), device=ro.device) if (perturb and nf > 0) else None

@@ -313,7 +313,11 @@ template <> struct Prec<NERFX_PREC_BF16> {
     static __device__ __forceinline__ float sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
     static __device__ __forceinline__ float silu(float x) { return x * sigmoid(x); }
     // output activations with hardware exp / log / rcp: their ~1e-6 error is far inside bf16's
-    static __device__ __forceinline__ float softplus(float x) { return __logf(1.0f + __expf(-fabsf(x))) + fmaxf(x, 0.0f); }
+    // (log(1 + e) rounds to 0 once e < 2^-24; log1p(e) = e to fp32 precision below 2.4e-4)
+    static __device__ __forceinline__ float softplus(float x) {
+        const float e = __expf(-fabsf(x));
+        return (e < 2.4e-4f ? e : __logf(1.0f + e)) + fmaxf(x, 0.0f);
+    }
     static __device__ __forceinline__ float widened_sigmoid(float x) {
         return fmaf(1.002f, __frcp_rn(1.0f + __expf(-x)), -0.001f);
     }

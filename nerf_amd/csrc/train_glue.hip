@@ -91,7 +91,7 @@ extern "C" int nerfx_gather_rays(const float* C, const float* ro, const float* r
                                  float* rd_out, void* stream) {
     NERFX_REQUIRE(n >= 0 && begin >= 0 && n_total >= 0, "negative size");
     if (n == 0) return 0;
-    NERFX_REQUIRE(n_total > 0 && (perm || begin + n <= n_total), "rays [%lld, +%lld) outside the %lld stored",
+    NERFX_REQUIRE(n_total > 0 && begin + n <= n_total, "rays [%lld, +%lld) outside the %lld stored",
                   (long long)begin, (long long)n, (long long)n_total);
     NERFX_REQUIRE(C && ro && rd && C_out && ro_out && rd_out, "a ray array is NULL");
     const int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);

@@ -167,7 +167,9 @@ def broadcast_parameters(module, src: int = 0, group=None) -> None:
     """Make every rank start from rank `src`'s weights (one flat broadcast)."""
     if world(group)[1] == 1:
         return
-    params = [p.data for p in module.parameters()]
+    # detach() shares the parameter's version counter (`.data` has its own), so the in-place copy
+    # below is seen by everything that caches derived state per version (ops.ModelHandle does)
+    params = [p.detach() for p in module.parameters()]
     flat = torch.cat([p.reshape(-1) for p in params])
     dist.broadcast(flat, src=src, group=group)
     torch._foreach_copy_(params, [v.view_as(p) for v, p in zip(flat.split([p.numel() for p in params]), params)])

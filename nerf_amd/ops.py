@@ -207,6 +207,7 @@ class ModelHandle:
         if self.device.type != "cuda":
             raise RuntimeError(f"nerf_amd runs on ROCm devices only: the model is on {self.device}")
         self._ptr = C.c_void_p()
+        self._epoch = 0
         tensors, arr = self._gather()
         with torch.cuda.device(self.device):
             check(lib.nerfx_model_create(C.byref(self.desc), arr, len(tensors), _stream(), C.byref(self._ptr)))
@@ -218,7 +219,11 @@ class ModelHandle:
         return tensors, arr
 
     def _current_stamp(self):
-        return tuple((t.data_ptr(), t._version) for t in self._sources)
+        return (self._epoch,) + tuple((t.data_ptr(), t._version) for t in self._sources)
+
+    def invalidate(self):
+        """Force a re-pack at the next use (see `ops.invalidate`)."""
+        self._epoch += 1
 
     def ready(self, prec: int):
         """The handle, with the packed copies of precision `prec` brought up to date if any
@@ -254,6 +259,18 @@ def handle_for(module) -> ModelHandle:
         h = ModelHandle(module)
         _HANDLES[module] = h
     return h
+
+
+def invalidate(module) -> None:
+    """Tell the kernels that `module`'s weights changed behind autograd's back.  The packed
+    weight copies are refreshed whenever a parameter's storage pointer or version counter
+    changes, which covers optimizers, `load_state_dict`, `copy_` under no_grad and `.to()`.
+    Writes through `p.data` (its version counter is separate from the parameter's) or through
+    a raw pointer (another library, a collective on `p.data`) leave no trace: call this after
+    them."""
+    h = _HANDLES.get(module)
+    if h is not None:
+        h.invalidate()
 
 
 # ---- MLP --------------------------------------------------------------------------------
@@ -578,6 +595,9 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
     for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
             raise RuntimeError(f"adam_step: `{name}` must be a contiguous fp32 ROCm tensor of {n} elements")
+    for name, t in (("inv_scale", inv_scale), ("found_inf", found_inf), ("step_in", step_in), ("step_out", step_out)):
+        if t is not None and not (t.is_cuda and t.device == param.device and t.dtype == torch.float32 and t.numel() == 1):
+            raise RuntimeError(f"adam_step: `{name}` must be one fp32 element on {param.device}")
     with torch.cuda.device(param.device):
         check(lib.nerfx_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lr, beta1, beta2, eps,
                                   weight_decay, _p(inv_scale), _p(found_inf), _p(step_in), _p(step_out), _stream()))

@@ -69,6 +69,25 @@ class Adam(torch.optim.Optimizer):
                 v.copy_(p.detach().reshape(-1))
                 p.data = v.view(p.shape)
 
+    def load_state_dict(self, state_dict) -> None:
+        """As torch's, then the flat buffers go back onto the parameters' device as fp32 (a
+        checkpoint read with map_location="cpu" would otherwise hand host pointers to the kernel)
+        and the parameters are re-adopted as views of the loaded flat buffer's values."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            params = group["params"]
+            state = self.state[params[0]]
+            dev = params[0].device
+            for key in ("flat_param", "exp_avg", "exp_avg_sq", "step", "flat_grad"):
+                state[key] = state[key].to(device=dev, dtype=torch.float32).contiguous()
+            state["which"] = int(state["which"])
+            state["sizes"] = [int(n) for n in state["sizes"]]
+            # the live parameters (what load_state_dict of the module set) win over the saved copy
+            with torch.no_grad():
+                for p, v in zip(params, state["flat_param"].split(state["sizes"])):
+                    v.copy_(p.detach().reshape(-1))
+                    p.data = v.view(p.shape)
+
     @property
     def steps_applied(self) -> int:
         """Number of updates actually applied to the first group (synchronises)."""
@@ -91,12 +110,14 @@ class Adam(torch.optim.Optimizer):
             self._ensure_flat(group)
             grad = flat_gradient(params)
             if grad is None:                                # gradients from elsewhere: gather them
+                if any(p.grad is None for p in params):
+                    # torch.optim.Adam leaves a parameter without a gradient untouched (moments
+                    # included); one flat update cannot, so say so instead of moving those weights
+                    raise RuntimeError("nerf_amd.optim.Adam: every parameter of a group needs a gradient "
+                                       "(put frozen parameters in a group of their own or leave them out)")
                 grad = state["flat_grad"]
                 for p, v in zip(params, grad.split(state["sizes"])):
-                    if p.grad is None:
-                        v.zero_()
-                    else:
-                        v.copy_(p.grad.reshape(-1))
+                    v.copy_(p.grad.reshape(-1))
             inv_scale = None if grad_scale is None else grad_scale.to(torch.float32).reciprocal().reshape(1)
             finf = None if found_inf is None else found_inf.to(torch.float32).reshape(1)
             w = state["which"]

@@ -347,44 +347,6 @@ def distill_step(teacher: "Model", student: "Model", rx: Tensor, rd: Tensor, del
     return loss.detach(), grads
 
 
-def reptile_meta_step(params: Params, enc_x, enc_d, activ, resid, batches, tn, tf, n_coarse, n_fine,
-                      optim: torch.optim.Optimizer, steps: int):
-    """reptile.py:112-160 without the scalers (perturb off): per batch, a copy of the field takes
-    `steps` SGD(momentum 0.9, lr = 1000 x the outer lr) steps, `field - copy` becomes the field's
-    gradient for `optim`, the loss reported is the field's loss on the batch BEFORE that update,
-    and the copy with its optimizer state is reset to the updated field.  `params` are leaf tensors owned by `optim`.
-    -> (losses, psnrs)."""
-    from copy import deepcopy
-    lr = optim.param_groups[0]["lr"] * 1e3
-    meta = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    meta_optim = torch.optim.SGD(list(meta.values()), lr=lr, momentum=0.9)
-    meta_state = deepcopy(meta_optim.state_dict())
-    losses, psnrs = [], []
-    for target, ro, rd in batches:
-        for _ in range(steps):
-            model = Model(meta, enc_x, enc_d, activ, resid)
-            *_, rgb_map = render_volume(model, model, ro, rd, tn, tf, n_coarse, n_fine)
-            loss = torch.nn.functional.mse_loss(rgb_map, target)
-            loss.backward()
-            meta_optim.step()
-            meta_optim.zero_grad(set_to_none=True)
-        with torch.no_grad():
-            for k, p in params.items():
-                p.grad = p - meta[k]
-            model = Model(params, enc_x, enc_d, activ, resid)
-            *_, rgb_map = render_volume(model, model, ro, rd, tn, tf, n_coarse, n_fine)
-            loss = torch.nn.functional.mse_loss(rgb_map, target)
-        optim.step()
-        optim.zero_grad(set_to_none=True)
-        with torch.no_grad():
-            for k, p in params.items():
-                meta[k].copy_(p)
-        meta_optim.load_state_dict(deepcopy(meta_state))
-        losses.append(float(loss))
-        psnrs.append(float(-10. * torch.log10(loss)))
-    return losses, psnrs
-
-
 def train_step(params: Params, enc_x, enc_d, activ, resid, ro, rd, target, tn, tf,
                n_coarse, n_fine, u_coarse, u_fine, optim: torch.optim.Optimizer):
     """train.py:75-86 with the GradScaler disabled: one render(train=True) + MSE

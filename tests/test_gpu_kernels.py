@@ -514,3 +514,53 @@ def test_limits_deepest_model_and_rejected_shapes(ops):
         m = bad().cuda()
         with pytest.raises((RuntimeError, NotImplementedError)):
             m(rx.cuda(), rd.cuda())
+
+
+def test_packed_weights_follow_every_kind_of_write(ops):
+    """The packed weight copies are refreshed after writes autograd can see (optimizer-style
+    in-place updates, a broadcast through detached views) and, for writes through `.data`,
+    after `ops.invalidate`."""
+    from nerf_amd import distributed as D
+    meta, g = load_golden("g3_mlp_student")
+    model = product_model(meta, g)
+    x, d = dev(g["rx"]), dev(g["rd"])
+    with torch.no_grad():
+        s0, _ = model(x, d)
+        model.sigma[0].bias.add_(0.5)                        # in place, under no_grad: version counter moves
+        s1, _ = model(x, d)
+        assert not torch.equal(s0, s1)
+        D.broadcast_parameters(model)                        # single process: a no-op, must not disturb anything
+        model.sigma[0].bias.data.add_(0.5)                   # through .data: invisible until invalidate()
+        ops.invalidate(model)
+        s2, _ = model(x, d)
+        assert not torch.equal(s1, s2)
+    om = oracle_model(meta, g)
+    om.params["sigma.0.bias"] = om.params["sigma.0.bias"] + 1.0
+    want, _ = om(g["rx"], g["rd"])
+    assert_close(s2.cpu(), want, rtol=1e-5, atol=2e-6, what="sigma after two bias writes")
+
+
+def test_bf16_density_head_keeps_tiny_densities(ops):
+    """softplus(x - 1) for strongly negative x is e^(x-1), not 0 (reference activations.py:33-35
+    uses log1p): with the last segment 1e10 long (ray.py:63) such a density still makes the last
+    sample opaque, so a bf16 render must paint the residual transmittance like the oracle does."""
+    from nerf_amd.core import BoundedVolumeRaymarcher
+    meta, g = load_golden("g3_mlp_student")
+    model = product_model(meta, g)
+    with torch.no_grad():
+        model.sigma[0].weight.zero_()
+        model.sigma[0].bias.fill_(-17.0)                     # sigma = softplus(-18) = 1.5e-8 everywhere
+    om = oracle_model(meta, g)
+    om.params["sigma.0.weight"] = torch.zeros_like(om.params["sigma.0.weight"])
+    om.params["sigma.0.bias"] = torch.full_like(om.params["sigma.0.bias"], -17.0)
+    gen = torch.Generator().manual_seed(11)
+    ro, rd = torch.rand(64, 3, generator=gen), torch.rand(64, 3, generator=gen) + 0.1
+    bvr = BoundedVolumeRaymarcher(2.0, 6.0, 16, 16)
+    with torch.no_grad():
+        _, w_ref, _, rgb_ref = O.render_volume(om, om, ro, rd, 2.0, 6.0, 16, 16)
+    assert float(w_ref[:, -1].min()) > 0.99                  # the far wall takes everything
+    ops.set_precision("bf16")
+    _, w, _, rgb = bvr.render_volume(model, model, dev(ro), dev(rd))
+    ops.set_precision(None)
+    assert_close(w[:, -1].cpu(), w_ref[:, -1], rtol=0, atol=1e-3, what="last-sample weight (bf16)")
+    assert_close(rgb.cpu(), rgb_ref, rtol=0, atol=1e-2, what="rgb (bf16)")

@@ -169,37 +169,6 @@ def test_from_torchscript_reads_a_scripted_field(tmp_path):
     assert set(want) == set(got) and all(torch.equal(want[k], got[k]) for k in want)
 
 
-def test_reptile_meta_objects_reset():
-    """build_meta / MetaStateHolder (reference reptile.py:24-82): the copy's SGD runs at 1000 x the
-    outer learning rate with momentum 0.9, and update() puts the copy back on the field's weights
-    with an empty momentum state."""
-    pytest.importorskip("nerf_amd._lib")
-    try:
-        from nerf_amd import reptile as R
-        from nerf_amd.core import NeRF, PositionalEncoding
-    except (OSError, RuntimeError) as e:                       # library not built on this machine
-        pytest.skip(str(e))
-    nerf = NeRF(PositionalEncoding(3, 2), PositionalEncoding(3, 2), 64, 2)
-    optim = torch.optim.Adam(nerf.parameters(), lr=5e-4)
-    scaler = torch.amp.GradScaler("cuda", enabled=False)
-    meta_nerf, meta_optim, meta_scaler = R.build_meta(nerf, optim, scaler)
-    assert isinstance(meta_optim, torch.optim.SGD)
-    assert meta_optim.param_groups[0]["lr"] == pytest.approx(0.5) and meta_optim.param_groups[0]["momentum"] == 0.9
-    assert meta_scaler is not scaler and meta_nerf is not nerf
-    holder = R.MetaStateHolder(nerf, meta_nerf, meta_optim, meta_scaler)
-    for p in meta_nerf.parameters():
-        p.grad = torch.ones_like(p)
-    meta_optim.step()
-    assert any(not torch.equal(a, b) for a, b in zip(nerf.parameters(), meta_nerf.parameters()))
-    assert len(meta_optim.state_dict()["state"]) > 0
-    with torch.no_grad():
-        for p in nerf.parameters():
-            p.add_(0.25)
-    holder.update()
-    assert all(torch.equal(a, b) for a, b in zip(nerf.parameters(), meta_nerf.parameters()))
-    assert len(meta_optim.state_dict()["state"]) == 0
-
-
 def test_async_tape_loads_keep_their_registers(tmp_path):
     """The bf16 backward chain issues its tape loads from inline asm, which the compiler does not
     track: in the compiled assembly nothing may touch their destination registers before the
