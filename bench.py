@@ -2,88 +2,152 @@
 
     python bench.py --gpus N --steps K --warmup W [--prec bf16|fp32] [--batch RAYS]
 
+With --gpus N > 1 and no launcher around it, the command starts its N ranks itself: the parent
+touches no GPU, spawns N fresh child processes of this same file (rank r on GPU r, rendezvous
+on 127.0.0.1) and relays rank 0's JSON line.  Under torchrun (WORLD_SIZE set) it is one rank.
+
 A step renders one 800x800 synthetic-ray frame per GPU (640,000 rays, U[0,1)^3 origins and
 un-normalised directions like the reference's bench, random-init NeRF(PE(3,6),PE(3,6),256,4),
-BVR(2,6,64,64), perturb off) through `BoundedVolumeRaymarcher.render_volume`, inputs and
-weights resident in HBM, outputs left on the device; for N > 1 each rank renders its own
-frame (the 40-view orbit is frame-sharded: no collective) and rank 0 gathers rgb+depth
-(16 B/ray) at the end of the step.  Rank 0 prints ONE JSON line.
+BVR(2,6,64,64), perturb off) through `BoundedVolumeRaymarcher.render_volume` -- the fused
+`nerfx_render_fwd` entry point, exactly what ships -- with inputs and weights resident in HBM
+and outputs left on the device.  For N > 1 each rank renders its own frame (the 40-view orbit is
+frame-sharded: no collective in the data path) and rank 0 gathers rgb + depth (16 B/ray) at the
+end of the step: `value` = rays of all ranks / max-over-ranks time ("weak" scaling).
 
-roofline: every launch of the fused MLP kernel inside the timed region is bracketed by HIP
-events on the launch stream; achieved = algorithmic FLOPs of those launches / their summed
-duration (so per-launch FLOPs / average launch duration), against the dense MFMA peak.
-cpu_baseline: the CPU oracle (oracle/nerf_oracle.py, torch CPU fp32) renders a 200x200
-frame of the same workload on this host's cores (rank 0, N = 1 only).
+Sub-records on the same JSON line (each timed in a region of its own, after `value`):
+  * `ray_sharded_frame`: ONE 800x800 frame sharded by rays over the N ranks (ceil(n / N) rays
+    each) through `nerf_amd.distributed.render_sharded`, the 16 B/ray gather to rank 0 and the
+    frame epilogue on rank 0 included: ms per frame, "strong" scaling;
+  * `roofline`: a separate pass of the same step issues the same kernels stage by stage through
+    the C ABI with HIP events (on the launch stream) around each: achieved = algorithmic FLOP of
+    the fused MLP launches / their summed duration, against the dense MFMA peak;
+  * `fp32`: the same step with exact-fp32 MFMA contractions (N = 1 only, 3 steps);
+  * `train`: 4,096-ray optimisation steps per GPU (render train=True with perturb, fused MSE,
+    backward, one flat gradient all-reduce for N > 1, unscale, Adam), ms per step;
+  * `cpu_baseline` (N = 1 only): the CPU oracle renders the reference's own 100x100 case on the
+    host cores, executing the colour head in the coarse pass as the reference does.
+
+--backend gloo --dry-run exercises launcher, process group, sharding, gathers and the JSON line
+on CPU with a stand-in per-ray function; it measures nothing (`value` is null).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_FULL = 641_024          # algorithmic FLOP per sample, full network
 FLOP_DENSITY = 433_664       # algorithmic FLOP per sample, trunk + density head
+FLOP_TRAIN_PER_RAY = 267_517_952      # coarse 64 x density + fine 128 x (forward + wgrad + dgrad)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+TN, TF, NC, NF = 2.0, 6.0, 64, 64
+WORKLOAD = "NeRF(PE(3,6),PE(3,6),256,4) random init, BVR(2,6,64c+64f)"
 
 
-def recorded_traffic(prec):
-    """HBM bytes per MLP launch from the committed PMC summary of this same command
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH doubled as gfx950 requires), or None."""
-    path = os.path.join(ROOT, "profiles", f"r1_bench_{prec}_pmc_hbm.json")
-    try:
-        with open(path) as f:
-            kernels = json.load(f)["kernels"]
-        k = next(v for name, v in kernels.items() if "mlp_fwd_kernel" in name)
-        return (k["fetch_corrected_KB"] + k["WRITE_SIZE_KB"]) * 1e3
-    except (OSError, KeyError, StopIteration, ValueError):
-        return None
+# ---- launcher --------------------------------------------------------------------------------
+def launch_ranks(n: int) -> int:
+    """Start `n` ranks of this file as child processes and wait for them.  Nothing here touches
+    a GPU: every rank initialises its own device in a fresh process."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
-def cpu_baseline(model, tn, tf, nc, nf):
+# ---- legs ------------------------------------------------------------------------------------
+def cpu_baseline(model):
+    """Config 1 of the benchmark definition: the 100x100 frame the reference's CPU path renders,
+    through the oracle with the colour head evaluated in the coarse pass too (renderer.py:91)."""
+    import torch
     from oracle import nerf_oracle as O
     params = {k: v.detach().cpu() for k, v in model.named_parameters()}
     f = O.positional_freq_bands(6)
     om = O.Model(params, O.make_encoder("pe", f), O.make_encoder("pe", f), "relu", True)
     g = torch.Generator().manual_seed(0)
-    H = W = 200
+    H = W = 100
     ro, rd = torch.rand(H * W, 3, generator=g), torch.rand(H * W, 3, generator=g)
-    O.infer(om, om, ro[:1000], rd[:1000], 10, 100, tn, tf, nc, nf, batch_size=16384)      # warm-up
+    O.infer(om, om, ro[:1000], rd[:1000], 10, 100, TN, TF, NC, NF, batch_size=16384, as_reference=True)   # warm-up
     best = float("inf")
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
-        O.infer(om, om, ro, rd, H, W, tn, tf, nc, nf, batch_size=16384)
+        O.infer(om, om, ro, rd, H, W, TN, TF, NC, NF, batch_size=16384, as_reference=True)
         best = min(best, time.perf_counter() - t0)
     return {"value": H * W / best, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{H}x{W} frame ({H * W:,} rays) of the same workload via oracle.infer, best of 2, "
-                      f"{best:.2f} s"}
+            "sample": f"{H}x{W} frame ({H * W:,} rays, batch 16,384) of the same workload via oracle.infer with the "
+                      f"coarse colour head executed as the reference does, best of 3, {best:.2f} s"}
 
 
-FLOP_TRAIN_PER_RAY = 267_517_952      # coarse 64 x density + fine 128 x (forward + wgrad + dgrad)
+def run_roofline(step, prec, steps):
+    """The same step through the staged path (identical kernel sequence, one C call and one event
+    pair per kernel): per-kernel durations, and the fused MLP's achieved FLOP/s."""
+    import nerf_amd.ops as ops
+    import torch
+    step()
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    try:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        log = ops.PROFILE
+    finally:
+        ops.PROFILE = None
+    stage_ms, mlp_flop, mlp_launches = {}, 0.0, 0
+    for stage, b, n, colour, a, z in log:
+        stage_ms[stage] = stage_ms.get(stage, 0.0) + a.elapsed_time(z)
+        if stage == "mlp":
+            mlp_flop += b * n * (FLOP_FULL if colour else FLOP_DENSITY)
+            mlp_launches += 1
+    achieved = mlp_flop / (stage_ms["mlp"] * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": "mlp_fwd_kernel", "achieved": achieved, "peak": PEAK_TFLOPS[prec],
+            "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[prec], "traffic": None, "launches": mlp_launches,
+            "avg_launch_ms": stage_ms["mlp"] / mlp_launches, "flop_per_launch": mlp_flop / mlp_launches,
+            "measured": f"HIP events around every kernel of {steps} staged steps after the timed region"}
+    return roof, {k: v / steps for k, v in stage_ms.items()}
 
 
-def bench_train(args, model, bvr, dev, rank, world, dist):
+def time_region(fn, steps, fence):
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    fence()
+    return time.perf_counter() - t0
+
+
+def train_leg(args, model, bvr, dev, rank, world, dist, prec, steps, warmup):
     """A step = one optimisation step on 4,096 rays per GPU exactly as nerf_amd.train.step runs it
     (render train=True, perturb on, fused MSE + PSNR, backward, gradient all-reduce for N > 1,
-    unscale_, Adam, scaler update; losses logged on the device and fetched once per LOG_EVERY
-    steps), batches resident in HBM.  --optim torch swaps nerf_amd.optim.Adam for torch.optim.Adam."""
+    unscale_, Adam, scaler update; losses stay on the device), batches resident in HBM."""
+    import torch
     import nerf_amd.ops as ops
-    from nerf_amd.distributed import average_gradients, broadcast_parameters
+    from nerf_amd.distributed import average_gradients, broadcast_parameters, seed_ranks
     from nerf_amd.optim import Adam
-    from nerf_amd.train import LOG_EVERY
     B = 4096
     broadcast_parameters(model)
+    seed_ranks(1234)                                         # independent perturb draws per rank
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     C, ro, rd = (torch.rand(B, 3, device=dev, generator=g) for _ in range(3))
-    eps = 1e-4 if args.prec == "bf16" else 1e-8
+    eps = 1e-4 if prec == "bf16" else 1e-8
     optim = (torch.optim.Adam if args.optim == "torch" else Adam)(model.parameters(), lr=5e-4, eps=eps)
-    scaler = torch.amp.GradScaler("cuda", enabled=args.prec == "bf16")
-    log = torch.zeros((args.warmup + args.steps, 2), device=dev)
+    scaler = torch.amp.GradScaler("cuda", enabled=prec == "bf16")
+    log = torch.zeros((warmup + steps, 2), device=dev)
     done = [0]
+    ops.set_precision(prec)
 
     def step():
         k = done[0]
@@ -96,41 +160,194 @@ def bench_train(args, model, bvr, dev, rank, world, dist):
         scaler.update()
         optim.zero_grad(set_to_none=True)
         done[0] = k + 1
-        if (k + 1) % LOG_EVERY == 0:
-            return log[k - LOG_EVERY + 1:k + 1].tolist()[-1][0]
-        return None
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    loss = log[args.warmup + args.steps - 1].tolist()[0]          # the end-of-pass fetch, inside the timed region
-    fence()
-    dt = time.perf_counter() - t0
+    dt = time_region(step, steps, fence)
+    loss = log[warmup + steps - 1].tolist()[0]
     t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.destroy_process_group()
     dt = t_max.item()
+    rate = world * B * steps / dt
+    achieved = rate / world * FLOP_TRAIN_PER_RAY / 1e12
+    return {"value": rate, "unit": "rays/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "dtype": prec, "rays_per_step_per_gpu": B, "optimizer": args.optim,
+            "roofline": {"bound": "mfma", "kernel": "whole step", "achieved": achieved, "peak": PEAK_TFLOPS[prec],
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[prec]},
+            "final_loss": loss}
+
+
+# ---- one rank --------------------------------------------------------------------------------
+def dry_run(args, rank, world):
+    """Launcher, process group, ray sharding, gathers and the JSON line on CPU tensors, with a
+    stand-in per-ray function in place of the kernels.  Measures nothing."""
+    import torch
+    import torch.distributed as dist
+    from nerf_amd.distributed import render_sharded, seed_ranks
+    if world > 1:
+        dist.init_process_group(args.backend)
+    seed_ranks(1234)
+    draw = torch.rand(4)                                     # what a perturbed render would draw first
+    n_rays = args.size * args.size
+    g = torch.Generator().manual_seed(0)
+    ro, rd = torch.rand(n_rays, 3, generator=g), torch.rand(n_rays, 3, generator=g)
+    fake = lambda o, d: ((o * d).sum(-1), torch.sin(o + 2 * d))
+    frame = render_sharded(fake, ro, rd, dst=0)
+    ok = True
     if rank == 0:
-        rate = world * B * args.steps / dt
-        achieved = rate / world * FLOP_TRAIN_PER_RAY / 1e12
-        print(json.dumps({
-            "metric": "rays/sec (training step, coarse64+fine64)", "value": rate, "unit": "rays/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
-            "config": {"workload": "4,096-ray optimisation step per GPU, NeRF(PE(3,6),PE(3,6),256,4), BVR(2,6,64c+64f), "
-                                   "perturb on, MSELoss, Adam (" + args.optim + "), GradScaler with bf16", "parallelism": f"data-parallel x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "whole step", "achieved": achieved, "peak": PEAK_TFLOPS[args.prec],
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.prec], "traffic": None},
-            "final_loss": loss}), flush=True)
+        depth, rgb = fake(ro, rd)
+        ok = torch.equal(frame, torch.cat([rgb, depth[:, None]], dim=1))
+    draws = [torch.zeros(4) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(draws, draw)
+        ok = ok and not any(torch.equal(draws[0], d) for d in draws[1:])
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "rays/sec (coarse64+fine64)", "value": None, "unit": "rays/s", "n_gpus": world,
+                          "dry_run": True, "backend": args.backend, "sharded_frame_identical": bool(ok)}), flush=True)
+    return 0 if ok else 1
+
+
+def run_rank(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import torch
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(args.backend, device_id=dev if args.backend == "nccl" else None)
+
+    import nerf_amd.ops as ops
+    from nerf_amd.core import BoundedVolumeRaymarcher, NeRF, PositionalEncoding
+    from nerf_amd.distributed import render_sharded
+
+    torch.manual_seed(0)
+    model = NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 6), 256, 4).to(dev)
+    bvr = BoundedVolumeRaymarcher(TN, TF, NC, NF)
+    n_rays = args.size * args.size
+    g = torch.Generator(device=dev).manual_seed(rank)
+    ro = torch.rand(n_rays, 3, device=dev, generator=g)
+    rd = torch.rand(n_rays, 3, device=dev, generator=g)
+    out = torch.zeros(n_rays, 4, device=dev)                 # rgb | depth, stays on the device
+    gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_max(dt):
+        t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        return t_max.item()
+
+    if args.mode == "train":
+        rec = train_leg(args, model, bvr, dev, rank, world, dist, args.prec, args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "rays/sec (training step, coarse64+fine64)", "value": rec["value"], "unit": "rays/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+                "config": {"workload": "4,096-ray optimisation step per GPU, " + WORKLOAD + ", perturb on, MSELoss, Adam ("
+                                       + args.optim + "), GradScaler with bf16", "parallelism": f"data-parallel x{world}"},
+                "roofline": dict(rec["roofline"], traffic=None), "final_loss": rec["final_loss"]}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
+    def render_step():
+        for s in range(0, n_rays, args.batch):
+            e = min(s + args.batch, n_rays)
+            *_, D, C = bvr.render_volume(model, model, ro[s:e], rd[s:e])
+            out[s:e, :3], out[s:e, 3] = C, D
+
+    def step():
+        render_step()
+        if world > 1:
+            dist.gather(out, gathered, dst=0)
+
+    # the frame every rank shares for the ray-sharded leg (same seed everywhere)
+    gs = torch.Generator(device=dev).manual_seed(12345)
+    ro_s = torch.rand(n_rays, 3, device=dev, generator=gs)
+    rd_s = torch.rand(n_rays, 3, device=dev, generator=gs)
+
+    def render_block(ro_b, rd_b):
+        depth = torch.empty((ro_b.shape[0],), device=dev)
+        rgb = torch.empty((ro_b.shape[0], 3), device=dev)
+        for s in range(0, ro_b.shape[0], args.batch):
+            e = min(s + args.batch, ro_b.shape[0])
+            *_, D, C = bvr.render_volume(model, model, ro_b[s:e], rd_b[s:e])
+            depth[s:e], rgb[s:e] = D, C
+        return depth, rgb
+
+    def sharded_step():
+        frame = render_sharded(render_block, ro_s, rd_s, dst=0)
+        if frame is not None:                                # rank 0: display frames, still on the device
+            ops.frame_finish(frame[:, 3], frame[:, :3], as_float=False, as_uint8=True)
+
+    result = None
+    with torch.no_grad():
+        ops.set_precision(args.prec)
+        for _ in range(args.warmup):
+            step()
+        dt = reduce_max(time_region(step, args.steps, fence))
+        for _ in range(max(1, min(args.warmup, 2))):
+            sharded_step()
+        k_sh = max(3, min(args.steps, 10))
+        dt_sh = reduce_max(time_region(sharded_step, k_sh, fence))
+        if rank == 0:
+            roof, stage_ms = run_roofline(render_step, args.prec, 2)
+            result = {
+                "metric": "rays/sec (coarse64+fine64)", "value": world * n_rays * args.steps / dt, "unit": "rays/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec,
+                "data": "synthetic",
+                "config": {"workload": f"{args.size}x{args.size} frame per GPU, {WORKLOAD}, perturb off, "
+                                       f"{args.batch} rays per render_volume call (nerfx_render_fwd)",
+                           "rays_per_step_per_gpu": n_rays, "parallelism": f"frame-sharded x{world}"},
+                "roofline": roof, "stage_ms_per_step": stage_ms,
+                "ray_sharded_frame": {
+                    "metric": f"ms per {args.size}x{args.size} frame", "ms_per_frame": dt_sh / k_sh * 1e3,
+                    "rays_per_s": n_rays * k_sh / dt_sh, "n_gpus": world, "steps": k_sh, "scaling": "strong",
+                    "rays_per_gpu": -(-n_rays // world),
+                    "includes": "render of ceil(n/N) rays per rank, 16 B/ray gather to rank 0, frame epilogue on rank 0"},
+            }
+        if world > 1:
+            dist.barrier()
+        if world == 1 and not args.no_fp32 and args.prec != "fp32":
+            ops.set_precision("fp32")
+            render_step()
+            dt32 = time_region(render_step, 3, fence)
+            roof32, _ = run_roofline(render_step, "fp32", 1)
+            result["fp32"] = {"value": n_rays * 3 / dt32, "unit": "rays/s", "ms_per_step": dt32 / 3 * 1e3, "steps": 3,
+                              "warmup": 1, "dtype": "fp32", "roofline": roof32}
+        ops.set_precision(args.prec)
+
+    if not args.no_train:
+        rec = train_leg(args, model, bvr, dev, rank, world, dist, args.prec, 20, 5)
+        if rank == 0:
+            result["train"] = rec
+    ops.set_precision(None)
+    if rank == 0:
+        if world == 1 and not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(model)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -142,97 +359,18 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="rays per render_volume call")
     ap.add_argument("--size", type=int, default=800, help="frame is size x size")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--optim", choices=("fused", "torch"), default="fused", help="--mode train: Adam implementation")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 sub-record")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-record")
+    ap.add_argument("--optim", choices=("fused", "torch"), default="fused", help="Adam implementation of the training leg")
     ap.add_argument("--mode", choices=("render", "train"), default="render",
-                    help="render: the headline metric; train: 4,096-ray optimisation steps (secondary)")
+                    help="render: the headline metric; train: 4,096-ray optimisation steps as the primary record")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="process-group backend (nccl = RCCL)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / sharding / gather check on CPU; measures nothing")
     args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-
-    import nerf_amd.ops as ops
-    from nerf_amd.core import BoundedVolumeRaymarcher, NeRF, PositionalEncoding
-
-    tn, tf, nc, nf = 2.0, 6.0, 64, 64
-    torch.manual_seed(0)
-    model = NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 6), 256, 4).to(dev)
-    bvr = BoundedVolumeRaymarcher(tn, tf, nc, nf)
-    n_rays = args.size * args.size
-    g = torch.Generator(device=dev).manual_seed(rank)
-    ro = torch.rand(n_rays, 3, device=dev, generator=g)
-    rd = torch.rand(n_rays, 3, device=dev, generator=g)
-    out = torch.zeros(n_rays, 4, device=dev)                 # rgb | depth, stays on the device
-    gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
-    ops.set_precision(args.prec)
-    if args.mode == "train":
-        return bench_train(args, model, bvr, dev, rank, world, dist)
-
-    def step():
-        for s in range(0, n_rays, args.batch):
-            e = min(s + args.batch, n_rays)
-            *_, D, C = bvr.render_volume(model, model, ro[s:e], rd[s:e])
-            out[s:e, :3], out[s:e, 3] = C, D
-        if world > 1:
-            dist.gather(out, gathered, dst=0)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        ops.PROFILE = []
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dt = time.perf_counter() - t0
-        log, ops.PROFILE = ops.PROFILE, None
-
-    t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    dt = t_max.item()
-
-    if rank == 0:
-        stage_ms, mlp_flop, mlp_launches = {}, 0.0, 0
-        for stage, b, n, colour, a, z in log:
-            stage_ms[stage] = stage_ms.get(stage, 0.0) + a.elapsed_time(z)
-            if stage == "mlp":
-                mlp_flop += b * n * (FLOP_FULL if colour else FLOP_DENSITY)
-                mlp_launches += 1
-        achieved = mlp_flop / (stage_ms["mlp"] * 1e-3) / 1e12
-        result = {
-            "metric": "rays/sec (coarse64+fine64)", "value": world * n_rays * args.steps / dt, "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec,
-            "data": "synthetic",
-            "config": {"workload": f"{args.size}x{args.size} frame per GPU, NeRF(PE(3,6),PE(3,6),256,4) random init, "
-                                   f"BVR(2,6,64c+64f), perturb off, {args.batch} rays per render_volume call",
-                       "rays_per_step_per_gpu": n_rays, "parallelism": f"frame-sharded x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "mlp_fwd_kernel", "achieved": achieved,
-                         "peak": PEAK_TFLOPS[args.prec], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.prec],
-                         "traffic": recorded_traffic(args.prec), "launches": mlp_launches,
-                         "avg_launch_ms": stage_ms["mlp"] / mlp_launches,
-                         "flop_per_launch": mlp_flop / mlp_launches},
-            "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
-        }
-        if world == 1 and not args.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(model, tn, tf, nc, nf)
-        print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

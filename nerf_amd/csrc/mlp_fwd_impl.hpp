@@ -405,7 +405,11 @@ __device__ __forceinline__ float activate(float x) {
     return x;                                                // ACT < 0: plain Linear
 }
 
+#ifdef NERFX_DIAG_MFMA16
+#include "mlp_runs_bf16_diag16.inc"     // timing diagnostic (wrong results): see tools/gen_mlp_runs_diag16.py
+#else
 #include "mlp_runs_bf16.inc"
+#endif
 
 // One acquired run of N units: unit i multiplies B operand b(i) into acc[i % NG].  The A
 // operands are read LOOKAHEAD units ahead of the MFMA that consumes them; the interleave is

@@ -233,25 +233,28 @@ class Model:
                            self.activ, self.resid, density_only)
 
 
-def render_coarse(model: Model, ro, rd, tn, tf, n, u, weights_only: bool):
-    """renderer.py:87-97."""
+def render_coarse(model: Model, ro, rd, tn, tf, n, u, weights_only: bool, as_reference: bool = False):
+    """renderer.py:87-97.  The reference evaluates the colour head even when only the weights are
+    used (renderer.py:91); `as_reference` does the same (for timing), otherwise it is skipped."""
     B = ro.size(0)
     rx, rds, t, delta = uniform_rays(ro, rd, tn, tf, n, u)
-    sigma, rgb = model(rx, rds, density_only=weights_only)
+    sigma, rgb = model(rx, rds, density_only=weights_only and not as_reference)
+    if weights_only:
+        rgb = None
     w, rgb_map = raymarch_volume(sigma.view(B, n), None if rgb is None else rgb.view(B, n, 3), delta)
     return t, w, rgb_map
 
 
 def render_volume(coarse: Model, fine: Model, ro: Tensor, rd: Tensor, tn: float, tf: float,
                   n_coarse: int, n_fine: int, u_coarse: Optional[Tensor] = None,
-                  u_fine: Optional[Tensor] = None):
+                  u_fine: Optional[Tensor] = None, as_reference: bool = False):
     """renderer.py:198-205 (+ :131-144 for the fine branch) ->
     (t, weights, depth_map, rgb_map).  `u_coarse` / `u_fine` are the uniforms the
     reference draws (in that order) when perturb=True; None = perturb off."""
     B = ro.size(0)
     if n_fine > 0:
         with torch.no_grad():                                     # renderer.py:133-135
-            t, w, _ = render_coarse(coarse, ro, rd, tn, tf, n_coarse, u_coarse, True)
+            t, w, _ = render_coarse(coarse, ro, rd, tn, tf, n_coarse, u_coarse, True, as_reference)
             rx, rds, t, delta = pdf_rays(ro, rd, t, w, n_fine, u_fine)
         n = n_coarse + n_fine
         sigma, rgb = fine(rx, rds)
@@ -271,13 +274,15 @@ def postprocess_frame(depth: Tensor, rgb: Tensor, H: int, W: int):
 
 
 @torch.no_grad()
-def infer(coarse: Model, fine: Model, ro, rd, H, W, tn, tf, n_coarse, n_fine, batch_size=16384):
-    """infer.py:42-68 -> (depth_map, rgb_map), both (H, W, 3) in [0, 255]."""
+def infer(coarse: Model, fine: Model, ro, rd, H, W, tn, tf, n_coarse, n_fine, batch_size=16384,
+          as_reference: bool = False):
+    """infer.py:42-68 -> (depth_map, rgb_map), both (H, W, 3) in [0, 255].  `as_reference`: also
+    execute the work the reference executes and discards (the coarse pass's colour head)."""
     n = ro.size(0)
     depth, rgb = torch.zeros(H * W), torch.zeros(H * W, 3)
     for s in range(0, n, batch_size):
         e = min(s + batch_size, n)
-        *_, D, C = render_volume(coarse, fine, ro[s:e], rd[s:e], tn, tf, n_coarse, n_fine)
+        *_, D, C = render_volume(coarse, fine, ro[s:e], rd[s:e], tn, tf, n_coarse, n_fine, as_reference=as_reference)
         depth[s:e], rgb[s:e] = D, C
     return postprocess_frame(depth, rgb, H, W)
 

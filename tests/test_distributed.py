@@ -158,3 +158,176 @@ def test_flat_gradient_detection():
     params[1].grad = None
     assert flat_gradient(params) is None
     assert flat_gradient([]) is None
+
+
+# ---- the real callers at world_size 2 -------------------------------------------------------
+# `nerf_amd.train.step` and `distributed.infer_sharded` are run as they ship; only the renderer
+# behind `raymarcher.render_volume` is a torch stand-in (the kernels need a GPU), so what is under
+# test is the control flow around it: sharding, gather, the all-reduce placed before `unscale_`,
+# the scaler's rank-consistent inf handling, per-rank seeding.
+class _Field(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+
+    def forward(self, ro, rd):
+        return self.net(torch.cat([ro, rd], dim=-1))
+
+
+class _Pointwise(torch.nn.Module):
+    """Per-ray arithmetic without a contraction: the same bits whatever the batch size."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor([0.3, -1.1, 2.0]))
+
+    def forward(self, ro, rd):
+        return ro * self.w
+
+
+class _StubMarcher:
+    """render_volume's signature and return tuple; colours come from the module, a uniform draw
+    stands for the perturbation, and `poison_call` injects an inf into that call's output."""
+
+    def __init__(self, poison_call=None, squash=True):
+        self.calls, self.poison_call, self.draws, self.squash = 0, poison_call, [], squash
+
+    def render_volume(self, coarse, fine, ro, rd, perturb=False, train=False):
+        u = torch.rand(1) if perturb else torch.zeros(1)
+        self.draws.append(float(u))
+        rgb = fine(ro, rd)
+        if self.squash:
+            rgb = torch.sigmoid(rgb)
+        if self.calls == self.poison_call:
+            rgb = rgb * float("inf")
+        self.calls += 1
+        depth = (ro * rd).sum(-1)
+        return None, None, depth, rgb
+
+
+class _PlainMSE(torch.nn.MSELoss):
+    """A subclass, so that `step` takes the caller's criterion instead of the fused loss kernel."""
+
+
+def _train_job(rank, world):
+    from nerf_amd import train as T
+    from nerf_amd.core import IndendityScheduler
+    torch.manual_seed(7)
+    net = _Field()
+    if rank == 1:
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.5)
+    D.broadcast_parameters(net, src=0)
+    D.seed_ranks(100)
+    optim = torch.optim.Adam(net.parameters(), lr=1e-2)
+    sched = IndendityScheduler(optim, 1, 1e-2)
+    scaler = torch.amp.GradScaler("cpu", enabled=True, init_scale=256.0, growth_interval=1000)
+    g = torch.Generator().manual_seed(50 + rank)                     # every rank has its own batches
+    batches = [tuple(torch.rand(32, 3, generator=g) for _ in range(3)) for _ in range(4)]
+    marcher = _StubMarcher(poison_call=2 if rank == 1 else None)     # rank 1 overflows in its third step
+    before_poison = None
+    snaps = []
+
+    class Loader(list):
+        pass
+
+    def snapshot_hook(_self, closure=None, _orig=optim.step):
+        snaps.append(torch.cat([p.detach().reshape(-1).clone() for p in net.parameters()]))
+        return _orig(closure)
+
+    optim.step = snapshot_hook.__get__(optim)
+    losses, psnrs, lrs = T.step(0, net, marcher, optim, sched, _PlainMSE(), scaler, Loader(batches), torch.device("cpu"),
+                                split="train", perturb=True, verbose=False)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    return dict(flat=flat, scale=float(scaler.get_scale()), losses=losses, lrs=lrs, optimizer_calls=len(snaps),
+                draws=marcher.draws, grads_none=all(p.grad is None for p in net.parameters()))
+
+
+def test_train_step_data_parallel_with_overflow_on_one_rank():
+    out = run(_train_job)
+    a, b = out[0], out[1]
+    assert torch.equal(a["flat"], b["flat"]), "ranks diverged"
+    assert torch.isfinite(a["flat"]).all()
+    # the overflow of rank 1 reached rank 0 through the all-reduce that precedes unscale_:
+    # both scalers backed off once (256 -> 128) and both skipped that step's update
+    assert a["scale"] == b["scale"] == 128.0
+    assert a["optimizer_calls"] == b["optimizer_calls"] == 3          # 4 steps, one skipped on both ranks
+    assert len(a["losses"]) == 4 and len(a["lrs"]) == 4
+    assert a["grads_none"] and b["grads_none"]
+    assert all(x != y for x, y in zip(a["draws"], b["draws"])), "ranks drew identical perturbations"
+
+
+def _train_reference_job(rank, world):
+    """Two ranks on the two halves of every batch == one process on the whole batches."""
+    from nerf_amd import train as T
+    from nerf_amd.core import IndendityScheduler
+    torch.manual_seed(7)
+    net = _Field()
+    optim = torch.optim.SGD(net.parameters(), lr=0.1)
+    sched = IndendityScheduler(optim, 1, 0.1)
+    scaler = torch.amp.GradScaler("cpu", enabled=False)
+    g = torch.Generator().manual_seed(50)
+    whole = [tuple(torch.rand(32, 3, generator=g) for _ in range(3)) for _ in range(3)]
+    s, e = D.shard_bounds(32, rank, world)
+    mine = [tuple(x[s:e] for x in batch) for batch in whole]
+    T.step(0, net, _StubMarcher(), optim, sched, _PlainMSE(), scaler, mine, torch.device("cpu"), split="train",
+           verbose=False)
+    return torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+
+
+def test_train_step_data_parallel_equals_whole_batch():
+    from nerf_amd import train as T
+    from nerf_amd.core import IndendityScheduler
+    torch.manual_seed(7)
+    net = _Field()
+    optim = torch.optim.SGD(net.parameters(), lr=0.1)
+    sched = IndendityScheduler(optim, 1, 0.1)
+    g = torch.Generator().manual_seed(50)
+    whole = [tuple(torch.rand(32, 3, generator=g) for _ in range(3)) for _ in range(3)]
+    T.step(0, net, _StubMarcher(), optim, sched, _PlainMSE(), torch.amp.GradScaler("cpu", enabled=False), whole,
+           torch.device("cpu"), split="train", verbose=False)
+    want = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    out = run(_train_reference_job)
+    assert torch.equal(out[0], out[1])
+    assert torch.allclose(out[0], want, rtol=1e-5, atol=1e-7)
+
+
+def _infer_job(rank, world):
+    from oracle import nerf_oracle as O
+    net = _Pointwise()
+    g = torch.Generator().manual_seed(9)
+    H, W = 7, 9
+    ro, rd = torch.rand(H * W, 3, generator=g), torch.rand(H * W, 3, generator=g)
+    marcher = _StubMarcher(squash=False)                     # single roundings only: batch-size invariant bits
+    depth, rgb = D.infer_sharded(net, net, marcher, ro, rd, H, W, batch_size=5, finish=O.postprocess_frame)
+    return (None if depth is None else depth.clone()), (None if rgb is None else rgb.clone()), marcher.calls
+
+
+def test_infer_sharded_matches_single_process():
+    from oracle import nerf_oracle as O
+    net = _Pointwise()
+    g = torch.Generator().manual_seed(9)
+    H, W = 7, 9
+    ro, rd = torch.rand(H * W, 3, generator=g), torch.rand(H * W, 3, generator=g)
+    with torch.no_grad():
+        *_, depth, rgb = _StubMarcher(squash=False).render_volume(net, net, ro, rd)
+    want_d, want_c = O.postprocess_frame(depth, rgb, H, W)
+    out = run(_infer_job)
+    assert out[1][0] is None and out[1][1] is None           # only rank 0 holds the frame
+    assert torch.equal(out[0][0], want_d) and torch.equal(out[0][1], want_c)   # incl. the frame-global depth range
+    assert out[0][2] == 7 and out[1][2] == 7                 # 32 and 31 rays in batches of 5
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2 --backend gloo --dry-run`: the parent starts two ranks itself."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run",
+                          "--size", "50"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["dry_run"] and line["sharded_frame_identical"]
