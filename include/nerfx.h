@@ -207,6 +207,21 @@ int nerfx_render_fwd(const nerfx_model_t* coarse, const nerfx_model_t* fine, int
                      void* workspace, int64_t workspace_bytes,
                      float* t, float* weights, float* depth_map, float* rgb_map, void* stream);
 
+/* The same render for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The
+ * workspace is a static device array inside the library, NERFX_STATIC_WORKSPACE_BYTES per GPU,
+ * held from the first call on a device until the process ends; the call allocates and frees
+ * nothing, and rejects (NERFX_E_ARG) more rays than nerfx_render_static_max_rays(nc, nf)
+ * (5,957 for 64 + 64 samples).  All calls on one GPU share that array: calls that overlap on the
+ * same GPU (two streams, two threads) race; calls on one stream are ordered and safe.  Results
+ * are bit-identical to nerfx_render_fwd's. */
+#define NERFX_STATIC_WORKSPACE_BYTES (16 * 1024 * 1024)
+int64_t nerfx_render_static_max_rays(int nc, int nf);
+int nerfx_render_fwd_static(const nerfx_model_t* coarse, const nerfx_model_t* fine, int precision,
+                            const float* ro, const float* rd, int64_t n_rays,
+                            float tn, float tf, int nc, int nf, const float* u_c, const float* u_f,
+                            float* t, float* weights, float* depth_map, float* rgb_map, void* stream);
+
 /* ---- camera rays in, display frames out (the callers either side of the path) ----------
  * Turn-around camera poses: turnaround_poses (data/path.py:104-128) with turnaround
  * (path.py:78-100) for each of `samples` steps of linspace(x0, x1, samples + 1)[:-1];

@@ -66,6 +66,9 @@ SIGNATURES = {
     "nerfx_render_workspace_bytes": (_l, [_l, _i, _i]),
     "nerfx_render_fwd": (_i, [_p, _p, _i, _p, _p, _l, _f, _f, _i, _i, _p, _p, _p, _l,
                               _p, _p, _p, _p, _p]),
+    "nerfx_render_static_max_rays": (_l, [_i, _i]),
+    "nerfx_render_fwd_static": (_i, [_p, _p, _i, _p, _p, _l, _f, _f, _i, _i, _p, _p,
+                                     _p, _p, _p, _p, _p]),
 }
 
 
