@@ -42,9 +42,21 @@ constexpr int MAX_LAYERS = 20;                  // 2*hd trunk + features + rgb.0
 constexpr int BIAS_STRIDE = 256;                // floats of const block per layer
 constexpr int MAX_TABLE = 1024;                 // floats per encoder table
 
+// A third stream layout beside the two public precisions: bf16 weights cut for
+// v_mfma_f32_16x16x32_bf16 (a unit = 16 output rows x 32 input features, lane l holds row l % 16
+// and inputs 8 (l / 16) .. + 7), read by the inference kernel of the 256-wide skip models
+// (mlp_fwd16_impl.hpp).  Same arithmetic as NERFX_PREC_BF16; the chip sustains a higher clock on
+// this MFMA shape.  Functions below take it wherever they take a precision.
+constexpr int NERFX_LAYOUT_M16 = 2;
+constexpr int N_LAYOUTS = 3;
+
 // slots (input features) per k-unit and k-units per 32-feature activation tile
-__host__ __device__ constexpr int slots_per_unit(int prec) { return prec == NERFX_PREC_BF16 ? 16 : 8; }
-__host__ __device__ constexpr int units_per_tile(int prec) { return prec == NERFX_PREC_BF16 ? 2 : 4; }
+__host__ __device__ constexpr int slots_per_unit(int prec) { return prec == NERFX_LAYOUT_M16 ? 32 : prec == NERFX_PREC_BF16 ? 16 : 8; }
+__host__ __device__ constexpr int units_per_tile(int prec) { return prec == NERFX_LAYOUT_M16 ? 1 : prec == NERFX_PREC_BF16 ? 2 : 4; }
+// output rows of one unit (= of one accumulator tile) and lanes that hold the same row group
+__host__ __device__ constexpr int rows_per_tile(int prec) { return prec == NERFX_LAYOUT_M16 ? 16 : 32; }
+// encoder k-units come in multiples of this (64 slots in both bf16 layouts)
+__host__ __device__ constexpr int enc_block(int prec) { return prec == NERFX_LAYOUT_M16 ? 2 : 4; }
 
 // Encoder slot order used inside the kernels.  A positional encoder first has its 3 raw
 // coordinates (and one zero) in slots 0..3 -- a fixed place whatever the number of
@@ -66,21 +78,23 @@ __host__ __device__ inline int enc_slot_col(int kind, int n, int slot) {
 __host__ __device__ inline int enc_units(int kind, int n, int prec) {
     const int slots = enc_raw_slots(kind) + (kind == NERFX_ENC_POSITIONAL ? 6 * n : 2 * n);
     const int units = (slots + slots_per_unit(prec) - 1) / slots_per_unit(prec);
-    return (units + ENC_BLOCK - 1) / ENC_BLOCK * ENC_BLOCK;
+    return (units + enc_block(prec) - 1) / enc_block(prec) * enc_block(prec);
 }
 // Entries of an encoder's pair-coefficient table (one float4 per pair-slot, covering the
 // padded units of either precision): angle of pair-slot k = c[k] . v' with v' = v (positional,
 // c = frequency on one axis) or 2 pi v (Fourier, c = b row).
 __host__ __device__ inline int enc_pair_slots(int kind, int n) { return enc_units(kind, n, NERFX_PREC_BF16) * 8; }
-// Encoder slot supplied by lane half h as element e of k-unit u.
+// Encoder slot supplied by lane group h (lane / rows_per_tile) as element e of k-unit u.
 __host__ __device__ inline int enc_unit_slot(int prec, int u, int h, int e) {
     const int spu = slots_per_unit(prec);
-    return spu * u + (spu / 2) * h + e;
+    return spu * u + (spu * rows_per_tile(prec) / 64) * h + e;
 }
 // Feature (row of the previous layer's 32x32 accumulator tiles) supplied by lane
 // half h as element e of chained k-unit u: the accumulator registers of a
 // v_mfma_f32_32x32x* result, reused in place as the next B operand.
 __host__ __device__ inline int chain_unit_feature(int prec, int u, int h, int e) {
+    // 16x16 accumulators: lane group h of tile T holds rows 16 T + 4 h + r; a k-unit is two tiles
+    if (prec == NERFX_LAYOUT_M16) return 32 * u + 16 * (e >> 2) + 4 * h + (e & 3);
     if (prec == NERFX_PREC_BF16) return 16 * u + 8 * (e >> 2) + 4 * h + (e & 3);
     return 8 * u + 4 * h + e;
 }
@@ -88,7 +102,7 @@ __host__ __device__ inline int chain_unit_feature(int prec, int u, int h, int e)
 // Output tiles a layer computes at a time: bounded by the accumulator registers that
 // fit beside the input and output fragments.
 __host__ __device__ constexpr int group_tiles(int prec, int n_tiles) {
-    const int cap = prec == NERFX_PREC_BF16 ? 2 : 4;
+    const int cap = prec == NERFX_PREC_BF16 ? 2 : 4;       // (four 16-row tiles in the M16 layout)
     return n_tiles < cap ? n_tiles : cap;
 }
 // Whether the training tape of this precision / activation carries sign words (Tape::signs):
@@ -102,7 +116,7 @@ __host__ __device__ constexpr int pad_to_piece(int units) {
 
 // One Linear layer as the kernels see it.
 struct LayerPlan {
-    int n_tiles;        // output tiles of 32 rows
+    int n_tiles;        // output tiles of rows_per_tile rows
     int out_dim;        // true rows
     int enc_units;      // leading k-units fed by an encoder (0 = none)
     int enc_kind, enc_n, enc_cols;   // that encoder and its width in the reference layout
@@ -147,6 +161,13 @@ __host__ __device__ inline int units_of(const LayerPlan& L) { return (L.n_tiles 
 
 // Fills `p` from a model description; returns 0 or an error code.
 int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p);
+// Models the M16 inference kernel takes: 129..256 wide, skip connection, depth 4 or 8, encoders
+// of at most 64 slots (positional up to 10 frequencies, Fourier up to 32 features).
+inline bool m16_supported(const nerfx_model_desc_t& d) {
+    return d.width > 128 && d.width <= 256 && d.resid && (d.depth == 4 || d.depth == 8) &&
+           enc_units(d.enc_x_kind, d.enc_x_n, NERFX_LAYOUT_M16) <= enc_block(NERFX_LAYOUT_M16) &&
+           enc_units(d.enc_d_kind, d.enc_d_n, NERFX_LAYOUT_M16) <= enc_block(NERFX_LAYOUT_M16);
+}
 
 // Samples per tape tile for n_points samples: whole workgroup blocks of either kernel family
 // and whole sample chunks of the weight-gradient kernel.
@@ -156,10 +177,11 @@ inline uint64_t tape_m_pad(int64_t n_points) { return ((uint64_t)n_points + 255)
 
 // The opaque handle of include/nerfx.h.
 struct nerfx_model {
-    nerfx::ModelPlan plan[2];          // indexed by NERFX_PREC_*
-    void* stream_dev[2];               // packed unit streams
+    nerfx::ModelPlan plan[nerfx::N_LAYOUTS];          // indexed by NERFX_PREC_* / NERFX_LAYOUT_M16
+    void* stream_dev[nerfx::N_LAYOUTS];               // packed unit streams
+    bool has_m16;                      // the M16 stream exists (see m16_supported)
     void* stream_bwd_dev[2];           // packed backward (transposed) unit streams
-    nerfx::LayerPlan* plans_dev[2];    // forward then backward layer plans (read by the pack kernel)
+    nerfx::LayerPlan* plans_dev[nerfx::N_LAYOUTS];    // forward then backward layer plans (read by the pack kernel)
     void* wtasks_dev[2];               // weight-gradient task tables (mlp_wgrad.hip)
     int n_wtasks[2];
     float* const_dev;                  // const block (same for both precisions)

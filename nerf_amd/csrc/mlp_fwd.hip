@@ -1,4 +1,6 @@
 // K2 entry points: validate, fill the launch arguments from the model plan, dispatch.
+#include <cstdlib>
+
 #include "mlp_bwd_impl.hpp"
 
 namespace nerfx {
@@ -9,6 +11,7 @@ int launch_mlp_fp32_bigenc(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_bigenc_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
 int launch_mlp_fp32_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
+int launch_mlp_m16(int activ, int hd, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_train(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_fp32_train(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_train_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
@@ -25,6 +28,12 @@ using namespace nerfx;
 // Diagnostic hook (only meaningful in -DNERFX_STAMPS builds): device buffer of 6 cycle buckets.
 static unsigned long long* g_stamps = nullptr;
 extern "C" void nerfx_debug_set_stamps(unsigned long long* device_buffer) { g_stamps = device_buffer; }
+
+// NERFX_NO_M16=1 in the environment keeps bf16 inference on the 32x32x16 kernels (A/B timing).
+static bool m16_enabled() {
+    static const bool on = [] { const char* e = getenv("NERFX_NO_M16"); return !(e && e[0] == '1'); }();
+    return on;
+}
 
 static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0, const float* p1, const float* t,
                       int64_t n_points, int n_samples, float* sigma, float* rgb, void* stream, void* tape = nullptr,
@@ -62,6 +71,12 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
         if (small_enc && p.wt == 8 && p.desc.resid && (p.hd == 2 || p.hd == 4))
             return (precision == NERFX_PREC_BF16 ? launch_mlp_bf16_train_fixed : launch_mlp_fp32_train_fixed)(p.desc.activ, p.hd, a, (hipStream_t)stream);
         return (precision == NERFX_PREC_BF16 ? launch_mlp_bf16_train : launch_mlp_fp32_train)(p.desc.activ, p.wt, a, (hipStream_t)stream);
+    }
+    if (precision == NERFX_PREC_BF16 && model->has_m16 && m16_enabled()) {     // the 16x16x32 kernel and its stream
+        const ModelPlan& p16 = model->plan[NERFX_LAYOUT_M16];
+        a.stream = (const char*)model->stream_dev[NERFX_LAYOUT_M16];
+        a.n_pieces = (uint32_t)((rgb ? p16.total_units : p16.trunk_units) / PIECE_UNITS);
+        return launch_mlp_m16(p.desc.activ, p.hd, a, (hipStream_t)stream);
     }
     // encoders that fit the kernels' register cache take the fast instantiations
     const bool big = a.ex_units > ENC_BLOCK || a.ed_units > ENC_BLOCK;

@@ -1,0 +1,302 @@
+// K2, bf16 inference form for the 256-wide skip models (depth 4 or 8, encoders of at most 64
+// slots): the same fused encode -> trunk -> density head -> colour head as mlp_fwd_impl.hpp, same
+// transposed orientation (weights = MFMA A operand from the LDS ring, samples = B columns,
+// activations never leave the register file), but built on v_mfma_f32_16x16x32_bf16.
+//
+// Why a second shape: the chip holds a higher clock under 16x16x32 than under 32x32x16 at equal
+// cycles per FLOP, and the 16-row output tile wastes half as much on the 3-row colour layer.
+//
+// Lane geometry.  A 16x16 accumulator has its sample on lane % 16 and rows 4 (lane / 16) + r in
+// its four registers.  A wavefront still owns 32 samples, as two blocks of 16 columns: lane l
+// carries sample 16 s + l % 16 of block s = 0, 1, and lane group q = l / 16 carries, for BOTH of
+// its samples, inputs 8 q .. 8 q + 7 of every k-unit (32 input features) and rows 4 q .. 4 q + 3
+// of every 16-row output tile.  One weight unit (1 KiB) feeds two MFMAs, one per block.  Two
+// adjacent output tiles, converted to bf16, are in place the next layer's B operand of one
+// k-unit (k order: chain_unit_feature(NERFX_LAYOUT_M16, ...), baked into the stream by the packer).
+//
+// A layer computes four output tiles (64 features) at a time: 8 accumulators of 4 registers.
+// Ring, hand-over protocol, persistent workgroups and const block are those of mlp_fwd_impl.hpp.
+#pragma once
+#include "mlp_fwd_impl.hpp"
+
+namespace nerfx {
+
+#include "mlp_runs_m16.inc"
+
+constexpr int M16 = NERFX_LAYOUT_M16;
+constexpr int M16_KU = 8;                       // k-units of a 256-wide activation
+constexpr int M16_ENC_KU = 2;                   // k-units of an encoder (64 slots)
+constexpr int M16_STASH_BYTES_PER_WAVE = M16_ENC_KU * 2 * UNIT_BYTES;
+static_assert(M16_ENC_KU == enc_block(M16), "encoder segment size");
+
+using Frag16 = bf16x8;
+struct Act16 { Frag16 f[M16_KU][2]; };          // one layer's activations: [k-unit][sample block]
+
+// B operand of encoder k-unit u for lane group q: slots 32 u + 8 q .. + 7 = pair-slots
+// 16 u + 4 q .. + 3 of the encoder's coefficient table (see encode_unit in mlp_fwd_impl.hpp).
+__device__ __forceinline__ Frag16 encode_unit16(lds_floats_t table, bool positional, int u, int q, float sx, float sy, float sz) {
+    using P = Prec<NERFX_PREC_BF16>;
+    const lds_floats_t c0 = table + 4 * (16 * u + 4 * q);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 c = NERFX_LDS_VEC(f32x4, c0 + 4 * i);
+        const float angle = fmaf(sz, c[2], fmaf(sy, c[1], __fmul_rn(sx, c[0])));
+        P::sincos_pair(angle, v[2 * i], v[2 * i + 1]);
+    }
+    if (positional && u == 0 && q == 0) { v[0] = sx; v[1] = sy; v[2] = sz; v[3] = 0.0f; }
+    return P::from_floats(v);
+}
+
+// Two adjacent 16-row tiles of one sample block -> the B operand of the k-unit they form.
+template <bool RELU>
+__device__ __forceinline__ Frag16 m16_from_acc(const f32x4& lo, const f32x4& hi) {
+    using P = Prec<NERFX_PREC_BF16>;
+    using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+    const u32x4 p = {P::pack2(lo[0], lo[1]), P::pack2(lo[2], lo[3]), P::pack2(hi[0], hi[1]), P::pack2(hi[2], hi[3])};
+    const Frag16 f = __builtin_bit_cast(Frag16, p);
+    return RELU ? P::relu(f) : f;
+}
+
+enum { M16_ENC_NONE = 0, M16_ENC_STASH = 1, M16_ENC_REGS = 2 };
+
+// One Linear layer of NT 16-row output tiles on [encoder k-units | CK chained k-units].
+//   ENC: where the encoder segment's B operands come from (the wave's LDS stash, or `encr`)
+//   SIGMA: also accumulate the density head's dot product on the fp32 activations (per block)
+template <int ACT, int NT, int CK, bool SIGMA, int ENC>
+__device__ __forceinline__ void linear16(WeightRing<RingBf16>& ring, lds_floats_t bias, int q, const Act16& hin, Act16& hout,
+                                         lds_floats_t sigw, float (&dot)[2], Stamps& st, uint32_t stash,
+                                         const Frag16 (&encr)[M16_ENC_KU][2]) {
+    using P = Prec<NERFX_PREC_BF16>;
+    static_assert(NT % 4 == 0 && (CK == 0 || CK == M16_KU), "full groups of four tiles on 0 or 256 chained inputs");
+    static_assert(CK > 0 || ENC != M16_ENC_NONE, "a layer needs an input");
+#pragma unroll
+    for (int grp = 0; grp < NT / 4; ++grp) {
+        f32x4 c[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c[t][0] = c[t][1] = NERFX_LDS_VEC(f32x4, bias + 16 * (grp * 4 + t) + 4 * q);
+        Frag16 a0, a1, a2, a3;
+        if constexpr (ENC != M16_ENC_NONE) {
+            st.mark(ST_EPILOGUE);
+            ring.template acquire<1>();
+            st.mark(ST_ACQUIRE);
+            const uint32_t p0 = (uint32_t)(uintptr_t)ring.unit_ptr(0);
+            if constexpr (ENC == M16_ENC_STASH)
+                m16_run8_stash(c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1], c[3][0], c[3][1], p0, stash,
+                               (uint32_t)ring.lane * 16u);
+            else
+                m16_run8(c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1], c[3][0], c[3][1], a0, a1, a2, a3, p0,
+                         encr[0][0], encr[0][1], encr[1][0], encr[1][1]);
+            st.mark(ST_RUN);
+            ring.template release<1>();
+        }
+        if constexpr (CK == M16_KU) {
+            st.mark(ST_EPILOGUE);
+            ring.template acquire<4>();
+            st.mark(ST_ACQUIRE);
+            uint32_t p[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[k] = (uint32_t)(uintptr_t)ring.unit_ptr(k * PIECE_UNITS);
+            // (the wave inside a hand-scheduled run goes first on its SIMD, as in mlp_fwd_impl.hpp)
+            __builtin_amdgcn_s_setprio(3);
+            m16_run16_out(c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1], c[3][0], c[3][1], a0, a1, a2, a3, p[0], p[1], p[2],
+                          hin.f[0][0], hin.f[0][1], hin.f[1][0], hin.f[1][1], hin.f[2][0], hin.f[2][1], hin.f[3][0], hin.f[3][1]);
+            m16_run16_in(c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1], c[3][0], c[3][1], a0, a1, a2, a3, p[2], p[3],
+                         hin.f[4][0], hin.f[4][1], hin.f[5][0], hin.f[5][1], hin.f[6][0], hin.f[6][1], hin.f[7][0], hin.f[7][1]);
+            __builtin_amdgcn_s_setprio(0);
+            st.mark(ST_RUN);
+            ring.template release<4>();
+        }
+        // epilogue: activation, density dot, conversion to the next layer's operands
+        constexpr bool packed_relu = ACT == NERFX_ACT_RELU && !SIGMA;
+        if constexpr (!packed_relu) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c[t][s][r] = activate<NERFX_PREC_BF16, ACT>(c[t][s][r]);
+        }
+        if constexpr (SIGMA) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 w = NERFX_LDS_VEC(f32x4, sigw + 16 * (grp * 4 + t) + 4 * q);
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dot[s] = fmaf(c[t][s][r], w[r], dot[s]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) hout.f[grp * 2 + j][s] = m16_from_acc<packed_relu>(c[2 * j][s], c[2 * j + 1][s]);
+    }
+}
+
+template <int ACT, int HD>
+__global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp_fwd16_kernel(const MlpArgs a) {
+    using RG = RingBf16;
+    using P = Prec<NERFX_PREC_BF16>;
+    constexpr int WAVES = RG::WAVES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __attribute__((address_space(3))) float* cst = (__attribute__((address_space(3))) float*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, col = lane & 15;
+
+    // LDS: [const block | per-wave encoding stash | weight ring]
+    const lds_bytes_t stash_base = (lds_bytes_t)smem + a.const_floats * (int)sizeof(float);
+    const lds_bytes_t my_stash = stash_base + wave * M16_STASH_BYTES_PER_WAVE + lane * 16;
+    WeightRing<RG> ring;
+    ring.init(a.stream, stash_base + WAVES * M16_STASH_BYTES_PER_WAVE, a.n_pieces, wave, lane);
+    for (int i = tid; i < a.const_floats; i += 64 * WAVES) cst[i] = a.consts[i];
+    __syncthreads();
+
+    const lds_floats_t sigw = cst + a.sigw_off;
+    const bool colour = a.rgb != nullptr;
+    constexpr int LAST = 2 * HD - 1;                                // last trunk layer feeds the density head
+    const bool x_positional = a.ex_kind == NERFX_ENC_POSITIONAL, d_positional = a.ed_kind == NERFX_ENC_POSITIONAL;
+    const float x_scale = x_positional ? 1.0f : 6.283185307179586f, d_scale = d_positional ? 1.0f : 6.283185307179586f;
+
+    Stamps st;
+    st.start();
+    for (uint32_t blk = blockIdx.x; blk < a.n_blocks; blk += gridDim.x) {
+        // ---- this lane's two samples (all four lane groups hold the same two) ----------
+        uint32_t m[2];
+        bool valid[2], poisoned[2];
+        float px[2], py[2], pz[2], dx[2], dy[2], dz[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            m[s] = blk * (32 * WAVES) + wave * 32 + 16 * s + col;
+            valid[s] = m[s] < a.n_points;
+            const uint32_t mc = valid[s] ? m[s] : a.n_points - 1;
+            if (a.t) {                                              // ray.py:132 / :226
+                const uint32_t ray = mc / a.n_samples;
+                const float tt = a.t[mc];
+                dx[s] = a.rd[3 * ray]; dy[s] = a.rd[3 * ray + 1]; dz[s] = a.rd[3 * ray + 2];
+                px[s] = __fadd_rn(a.ro[3 * ray], __fmul_rn(dx[s], tt));
+                py[s] = __fadd_rn(a.ro[3 * ray + 1], __fmul_rn(dy[s], tt));
+                pz[s] = __fadd_rn(a.ro[3 * ray + 2], __fmul_rn(dz[s], tt));
+            } else {
+                px[s] = a.ro[3 * (size_t)mc]; py[s] = a.ro[3 * (size_t)mc + 1]; pz[s] = a.ro[3 * (size_t)mc + 2];
+                dx[s] = a.rd[3 * (size_t)mc]; dy[s] = a.rd[3 * (size_t)mc + 1]; dz[s] = a.rd[3 * (size_t)mc + 2];
+            }
+            // A non-finite input poisons every feature in the reference (model.py:68-78).
+            const float probe = (px[s] + py[s] + pz[s]) + (colour ? (dx[s] + dy[s] + dz[s]) : 0.0f);
+            poisoned[s] = !(fabsf(probe) <= 3.0e38f);
+        }
+        st.mark(ST_PROLOGUE);
+        // phi_x is consumed twice (layer 0 and the skip layer): its B operands are parked in the
+        // wave's LDS stash, from where the encoder blocks read them.
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float sx = __fmul_rn(x_scale, px[s]), sy = __fmul_rn(x_scale, py[s]), sz = __fmul_rn(x_scale, pz[s]);
+#pragma unroll
+            for (int u = 0; u < M16_ENC_KU; ++u)
+                *reinterpret_cast<__attribute__((address_space(3))) Frag16*>(my_stash + (2 * u + s) * UNIT_BYTES) =
+                    encode_unit16(cst + a.tabx_off, x_positional, u, q, sx, sy, sz);
+        }
+        // same wave reads it back: LDS is in order per wave
+        const uint32_t stash = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(stash_base + wave * M16_STASH_BYTES_PER_WAVE));
+        st.mark(ST_ENCODE);
+
+        Act16 A, B;                                                 // ping-pong activations
+        Frag16 encr[M16_ENC_KU][2] = {};
+        float dot[2] = {0.0f, 0.0f};
+        // ---- fc_1 then fc_2; fc_2's first layer sees [phi_x | h] (model.py:71-73).  Layer 0
+        // writes A; the remaining 2 HD - 1 trunk layers alternate A -> B, B -> A and end in B.
+        linear16<ACT, 16, 0, false, M16_ENC_STASH>(ring, cst, q, B, A, sigw, dot, st, stash, encr);
+#pragma unroll
+        for (int li = 1; li + 1 <= LAST - 1; li += 2) {
+            if (li == HD) linear16<ACT, 16, M16_KU, false, M16_ENC_STASH>(ring, cst + li * BIAS_STRIDE, q, A, B, sigw, dot, st, stash, encr);
+            else linear16<ACT, 16, M16_KU, false, M16_ENC_NONE>(ring, cst + li * BIAS_STRIDE, q, A, B, sigw, dot, st, stash, encr);
+            if (li + 1 == HD) linear16<ACT, 16, M16_KU, false, M16_ENC_STASH>(ring, cst + (li + 1) * BIAS_STRIDE, q, B, A, sigw, dot, st, stash, encr);
+            else linear16<ACT, 16, M16_KU, false, M16_ENC_NONE>(ring, cst + (li + 1) * BIAS_STRIDE, q, B, A, sigw, dot, st, stash, encr);
+        }
+        static_assert(LAST != HD, "the skip layer is never the last trunk layer (HD >= 2)");
+        linear16<ACT, 16, M16_KU, true, M16_ENC_NONE>(ring, cst + LAST * BIAS_STRIDE, q, A, B, sigw, dot, st, stash, encr);
+        // ---- density head (model.py:75, activations.py:33-35): lane groups 0 / 1 store blocks 0 / 1
+        st.mark(ST_EPILOGUE);
+        {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                dot[s] += __shfl_xor(dot[s], 16, 64);
+                dot[s] += __shfl_xor(dot[s], 32, 64);
+            }
+            const int s = q & 1;
+            float sg = P::softplus(((s ? dot[1] : dot[0]) + cst[a.sigb_off]) - 1.0f);
+            if (s ? poisoned[1] : poisoned[0]) sg = __builtin_nanf("");
+            if (q < 2 && (s ? valid[1] : valid[0])) a.sigma[s ? m[1] : m[0]] = sg;
+        }
+        st.mark(ST_HEADS);
+        if (colour) {
+            int li = LAST + 1;
+            // ---- features: Linear without activation (model.py:51, :76): B -> A ------------
+            linear16<-1, 16, M16_KU, false, M16_ENC_NONE>(ring, cst + li * BIAS_STRIDE, q, B, A, sigw, dot, st, stash, encr);
+            ++li;
+            // ---- rgb.0 on [phi_d | features] (model.py:53, :76): A -> first half of B ------
+            st.mark(ST_EPILOGUE);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float sx = __fmul_rn(d_scale, dx[s]), sy = __fmul_rn(d_scale, dy[s]), sz = __fmul_rn(d_scale, dz[s]);
+#pragma unroll
+                for (int u = 0; u < M16_ENC_KU; ++u) encr[u][s] = encode_unit16(cst + a.tabd_off, d_positional, u, q, sx, sy, sz);
+            }
+            st.mark(ST_ENCODE);
+            linear16<ACT, 8, M16_KU, false, M16_ENC_REGS>(ring, cst + li * BIAS_STRIDE, q, A, B, sigw, dot, st, stash, encr);
+            ++li;
+            // ---- rgb.2 (one 16-row tile on 128 inputs: 4 units in one piece) + widened sigmoid
+            // (model.py:54, activations.py:18-20)
+            st.mark(ST_EPILOGUE);
+            ring.template acquire<1>();
+            st.mark(ST_ACQUIRE);
+            f32x4 out[2];
+            out[0] = out[1] = NERFX_LDS_VEC(f32x4, cst + li * BIAS_STRIDE + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const Frag16 w = NERFX_LDS_VEC(bf16x8, ring.unit_ptr(k));
+                out[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, B.f[k][0], out[0], 0, 0, 0);
+                out[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, B.f[k][1], out[1], 0, 0, 0);
+            }
+            st.mark(ST_RUN);
+            ring.template release<1>();
+            if (q == 0) {                                           // rows 0..2 of the tile sit in lane group 0
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    if (valid[s]) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            float v = P::widened_sigmoid(out[s][ch]);
+                            if (poisoned[s]) v = __builtin_nanf("");
+                            a.rgb[3 * (size_t)m[s] + ch] = v;
+                        }
+                    }
+            }
+        }
+        st.mark(ST_HEADS);
+    }
+    st.flush(a.stamps, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int ACT, int HD>
+static int launch_cfg16(const MlpArgs& a, hipStream_t stream) {
+    using RG = RingBf16;
+    auto kern = mlp_fwd16_kernel<ACT, HD>;
+    const size_t lds_bytes = (size_t)a.const_floats * sizeof(float) + (size_t)RG::PIECES * PIECE_UNITS * UNIT_BYTES +
+                             (size_t)RG::WAVES * M16_STASH_BYTES_PER_WAVE;
+    NERFX_REQUIRE(lds_bytes <= 160 * 1024, "model needs %zu bytes of LDS per workgroup", lds_bytes);
+    static thread_local size_t configured = 0;
+    if (lds_bytes > configured) {
+        NERFX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        configured = lds_bytes;
+    }
+    int dev = 0, cus = 256;
+    NERFX_HIP(hipGetDevice(&dev));
+    NERFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const uint32_t grid = std::min<uint32_t>(a.n_blocks, (uint32_t)cus);      // persistent workgroups, one per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RG::WAVES), lds_bytes, stream, a);
+    return launch_status("mlp_fwd16_kernel");
+}
+
+}  // namespace nerfx

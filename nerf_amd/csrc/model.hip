@@ -24,6 +24,7 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
     auto pow2_tiles = [](int dim) { int t = 1; while (32 * t < dim) t *= 2; return t; };
     p.wt = pow2_tiles(d.width);          // tiles are padded to a power of two so that a
     p.rt = pow2_tiles(d.width / 2);      // k-block of n_tiles units never straddles a ring chunk
+    const int tiles_per_32 = 32 / rows_per_tile(prec);              // output tiles per 32 rows
     p.hd = d.depth / 2;
     p.n_layers = 2 * p.hd + 3;
     const int ex_cols = enc_width(d.enc_x_kind, d.enc_x_n), ed_cols = enc_width(d.enc_d_kind, d.enc_d_n);
@@ -32,12 +33,12 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
     for (int li = 0; li < p.n_layers; ++li) {
         LayerPlan& L = p.layer[li];
         L = LayerPlan{};
-        L.n_tiles = p.wt; L.out_dim = d.width; L.chain_tiles = p.wt; L.chain_dim = d.width;
+        L.n_tiles = p.wt * tiles_per_32; L.out_dim = d.width; L.chain_tiles = p.wt; L.chain_dim = d.width;
         const bool with_x = li == 0 || (li == p.hd && d.resid);
         if (with_x) { L.enc_units = ex_units; L.enc_kind = d.enc_x_kind; L.enc_n = d.enc_x_n; L.enc_cols = ex_cols; }
         if (li == 0) { L.chain_tiles = 0; L.chain_dim = 0; }
         if (li == 2 * p.hd + 1) {                                   // rgb.0
-            L.n_tiles = p.rt; L.out_dim = d.width / 2;
+            L.n_tiles = p.rt * tiles_per_32; L.out_dim = d.width / 2;
             L.enc_units = ed_units; L.enc_kind = d.enc_d_kind; L.enc_n = d.enc_d_n; L.enc_cols = ed_cols;
         }
         if (li == 2 * p.hd + 2) {                                   // rgb.2
@@ -45,7 +46,7 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
         }
         L.in_dim = L.enc_cols + L.chain_dim;
         L.group = group_tiles(prec, L.n_tiles);
-        L.enc_seg = L.enc_units / ENC_BLOCK * pad_to_piece(ENC_BLOCK * L.group);   // block-wise padding
+        L.enc_seg = L.enc_units / enc_block(prec) * pad_to_piece(enc_block(prec) * L.group);   // block-wise padding
         L.chain_seg = pad_to_piece(L.chain_tiles * units_per_tile(prec) * L.group);
         L.unit0 = unit;
         unit += units_of(L);
@@ -88,7 +89,8 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
 // One thread per packed 16-byte lane slice of one layer (padding units included).
 template <int PREC>
 __device__ __forceinline__ void pack_layer(const float* __restrict__ W, const LayerPlan& L, void* __restrict__ stream) {
-    constexpr int EPL = PREC == NERFX_PREC_BF16 ? 8 : 4;          // elements per lane per unit
+    constexpr int EPL = PREC == NERFX_PREC_FP32 ? 4 : 8;          // elements per lane per unit
+    constexpr int ROWS = rows_per_tile(PREC), EB = enc_block(PREC);
     const int group_units = L.enc_seg + L.chain_seg;
     const int64_t n_slices = (int64_t)units_of(L) * 64;
     for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < n_slices; s += (int64_t)gridDim.x * 256) {
@@ -100,18 +102,18 @@ __device__ __forceinline__ void pack_layer(const float* __restrict__ W, const La
         int ku, t;                                                  // [k-unit][tile in group]
         bool live;
         if (enc) {                                                  // ENC_BLOCK k-units per padded block
-            const int block_units = pad_to_piece(ENC_BLOCK * L.group);
+            const int block_units = pad_to_piece(EB * L.group);
             const int eb = in_group / block_units, within = in_group - eb * block_units;
-            ku = eb * ENC_BLOCK + within / L.group;
+            ku = eb * EB + within / L.group;
             t = within % L.group;
-            live = within < ENC_BLOCK * L.group;
+            live = within < EB * L.group;
         } else {
             in_group -= L.enc_seg;
             ku = in_group / L.group;
             t = in_group - ku * L.group;
             live = ku < L.chain_tiles * units_per_tile(PREC);
         }
-        const int row = 32 * (grp * L.group + t) + (lane & 31), h = lane >> 5;
+        const int row = ROWS * (grp * L.group + t) + lane % ROWS, h = lane / ROWS;
         float v[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
@@ -130,7 +132,7 @@ __device__ __forceinline__ void pack_layer(const float* __restrict__ W, const La
             }
         }
         char* dst = (char*)stream + (L.unit0 + unit) * UNIT_BYTES + lane * 16;
-        if (PREC == NERFX_PREC_BF16) {
+        if (PREC != NERFX_PREC_FP32) {
             __bf16 b[8];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) b[e] = (__bf16)v[e];
@@ -194,6 +196,13 @@ static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipSt
     const ModelPlan& p0 = m->plan[0];
     const nerfx_model_desc_t& d = p0.desc;
     for (int i = 0; i < m->n_tensors; ++i) NERFX_REQUIRE(tensors[i] != nullptr, "tensor %d is NULL", i);
+    if ((mask >> NERFX_PREC_BF16 & 1) && m->has_m16) {              // the bf16 inference stream of the M16 kernel
+        const ModelPlan& p = m->plan[NERFX_LAYOUT_M16];
+        PackSources src{};
+        for (int li = 0; li < p.n_layers; ++li) src.w[li] = tensors[tensor_index(p, li, false)];
+        hipLaunchKernelGGL(pack_streams_kernel<NERFX_LAYOUT_M16>, dim3(64, p.n_layers), dim3(256), 0, stream,
+                           m->plans_dev[NERFX_LAYOUT_M16], p.n_layers, src, m->stream_dev[NERFX_LAYOUT_M16], nullptr);
+    }
     for (int prec = 0; prec < 2; ++prec) {
         if (!(mask >> prec & 1)) continue;
         const ModelPlan& p = m->plan[prec];
@@ -236,8 +245,9 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
     *out = nullptr;
     nerfx_model* m = new (std::nothrow) nerfx_model{};
     if (!m) return fail(NERFX_E_NOMEM, "out of host memory");
-    for (int prec = 0; prec < 2; ++prec)
+    for (int prec = 0; prec < N_LAYOUTS; ++prec)
         if (int e = make_plan(*desc, prec, m->plan[prec])) { delete m; return e; }
+    m->has_m16 = m16_supported(*desc);
     m->n_tensors = 2 + 2 * desc->depth + 8;
     if (n_tensors != m->n_tensors) {
         const int want = m->n_tensors;
@@ -245,8 +255,9 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
         return fail(NERFX_E_ARG, "expected %d tensors for depth %d, got %d", want, desc->depth, n_tensors);
     }
     hipError_t e = hipGetDevice(&m->device);
-    for (int prec = 0; prec < 2 && e == hipSuccess; ++prec)
-        e = hipMalloc(&m->stream_dev[prec], (size_t)m->plan[prec].total_units * UNIT_BYTES);
+    for (int prec = 0; prec < N_LAYOUTS && e == hipSuccess; ++prec)
+        if (prec != NERFX_LAYOUT_M16 || m->has_m16)
+            e = hipMalloc(&m->stream_dev[prec], (size_t)m->plan[prec].total_units * UNIT_BYTES);
     for (int prec = 0; prec < 2 && e == hipSuccess; ++prec)
         e = hipMalloc(&m->stream_bwd_dev[prec], (size_t)m->plan[prec].bwd_units * UNIT_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&m->const_dev, (size_t)m->plan[0].const_floats * sizeof(float));
@@ -254,7 +265,8 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
         nerfx_model_destroy(m);
         return fail(e == hipErrorOutOfMemory ? NERFX_E_NOMEM : NERFX_E_HIP, "model allocation failed: %s", hipGetErrorString(e));
     }
-    for (int prec = 0; prec < 2 && e == hipSuccess; ++prec) {           // the layer plans the pack kernel reads
+    for (int prec = 0; prec < N_LAYOUTS && e == hipSuccess; ++prec) {   // the layer plans the pack kernel reads
+        if (prec == NERFX_LAYOUT_M16 && !m->has_m16) continue;
         const ModelPlan& p = m->plan[prec];
         LayerPlan all[2 * MAX_LAYERS];
         for (int li = 0; li < p.n_layers + p.n_bwd; ++li) all[li] = li < p.n_layers ? p.layer[li] : p.bwd[li - p.n_layers];
@@ -288,13 +300,13 @@ extern "C" int nerfx_model_refresh_precision(nerfx_model_t* m, const float* cons
 
 extern "C" void nerfx_model_destroy(nerfx_model_t* m) {
     if (!m) return;
-    for (int prec = 0; prec < 2; ++prec)
+    for (int prec = 0; prec < N_LAYOUTS; ++prec)
         if (m->stream_dev[prec]) (void)hipFree(m->stream_dev[prec]);
     for (int prec = 0; prec < 2; ++prec)
         if (m->stream_bwd_dev[prec]) (void)hipFree(m->stream_bwd_dev[prec]);
     for (int prec = 0; prec < 2; ++prec)
         if (m->wtasks_dev[prec]) (void)hipFree(m->wtasks_dev[prec]);
-    for (int prec = 0; prec < 2; ++prec)
+    for (int prec = 0; prec < N_LAYOUTS; ++prec)
         if (m->plans_dev[prec]) (void)hipFree(m->plans_dev[prec]);
     if (m->const_dev) (void)hipFree(m->const_dev);
     delete m;
