@@ -15,7 +15,23 @@
 // k-unit (k order: chain_unit_feature(NERFX_LAYOUT_M16, ...), baked into the stream by the packer).
 //
 // A layer computes four output tiles (64 features) at a time: 8 accumulators of 4 registers.
-// Ring, hand-over protocol, persistent workgroups and const block are those of mlp_fwd_impl.hpp.
+//
+// Phases.  A workgroup is 8 wavefronts, two per SIMD (waves w and w + 4 share one).  Waves 0..3
+// (group 0) and waves 4..7 (group 1) run the same program half a step apart: while one group is
+// inside an MFMA run, the other converts its results, refills the weight ring and prepares its
+// next run, so the matrix pipe of every SIMD always has one wave feeding it and the other wave's
+// VALU / LDS-DMA work fills the issue slots between the MFMAs.  Every run is bracketed by two
+// workgroup barriers (inside the hand-scheduled blocks); group 1 meets one extra barrier at the
+// start and group 0 one at the end, which is all it takes to keep the groups in anti-phase.
+//
+// Weight ring.  The stream is consumed in SEGMENTS (one group of output tiles of one layer: its
+// encoder units, then its chained units; 8, 32 or 40 units).  Segment s is read by group 0 in
+// phase 2 s and by group 1 in phase 2 s + 1; after that group 1 refills the first half of its
+// slot and, one phase later, group 0 the second half (each wave a quarter of a half), with the
+// stream units that lie one ring length ahead.  A wave waits for its own loads before its next
+// barrier, so what was requested in phase p is visible to everybody from phase p + 1.  With a
+// ring of two maximal segments every unit of segment n has been requested by phase 2 n - 2 (its
+// first units, which are read ahead before the barrier) resp. 2 n - 1.
 #pragma once
 #include "mlp_fwd_impl.hpp"
 
@@ -28,6 +44,77 @@ constexpr int M16_KU = 8;                       // k-units of a 256-wide activat
 constexpr int M16_ENC_KU = 2;                   // k-units of an encoder (64 slots)
 constexpr int M16_STASH_BYTES_PER_WAVE = M16_ENC_KU * 2 * UNIT_BYTES;
 static_assert(M16_ENC_KU == enc_block(M16), "encoder segment size");
+
+constexpr int M16_RING_UNITS = 80;              // two segments of 40 units
+static_assert(M16_RING_UNITS % PIECE_UNITS == 0, "a piece never straddles the end of the ring");
+
+struct PhasedRing {
+    static constexpr int CHUNK = 4;              // units per refill chunk: one LDS base (M0), four loads
+    const char* src;             // stream base (wave-uniform; lanes add their own 32-bit offset)
+    lds_bytes_t lds;             // ring base
+    uint32_t n_units;            // stream length of this launch, in units
+    uint32_t cons, cons_stream;  // ring / stream unit index of the current segment's first unit
+    uint32_t prev_cons, prev_stream, prev_units;   // group 0: the slot whose second half is still to refill
+    uint32_t fill_ring, fill_stream, fill_chunks;  // this group's refill duty of the current phase, in chunks
+    int wave, lane, group, gw;   // group = wave / 4, gw = wave % 4
+
+    __device__ __forceinline__ static uint32_t wrap_ring(uint32_t u) { return u >= M16_RING_UNITS ? u - M16_RING_UNITS : u; }
+    __device__ __forceinline__ uint32_t wrap_stream(uint32_t u) const { return u >= n_units ? u - n_units : u; }
+    // Four consecutive units (4-aligned in ring and stream, so they never straddle either end:
+    // segments start at multiples of 8 in both) with ONE LDS base: the instruction offset moves
+    // the global and the LDS address alike.  LDS-DMA instructions of a wave that each carry their
+    // own base (M0) issue a full L2 round trip apart; with a shared base they go back to back.
+    __device__ __forceinline__ void load_chunk(uint32_t ring_unit, uint32_t stream_unit) {
+        const char* g = src + (size_t)wrap_stream(stream_unit) * UNIT_BYTES + (uint32_t)(lane * 16);
+        lds_bytes_t l = lds + wrap_ring(ring_unit) * UNIT_BYTES;
+        const auto gp = (const void __attribute__((address_space(1)))*)g;
+        const auto lp = (void __attribute__((address_space(3)))*)l;
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 0 * UNIT_BYTES, 0);
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 1 * UNIT_BYTES, 0);
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 2 * UNIT_BYTES, 0);
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 3 * UNIT_BYTES, 0);
+    }
+    __device__ __forceinline__ void init(const char* s, lds_bytes_t l, uint32_t nu, int w, int ln) {
+        src = s; lds = l; n_units = nu; wave = w; lane = ln;
+        group = w >> 2; gw = w & 3;
+        cons = 0; cons_stream = 0; prev_cons = 0; prev_stream = 0; prev_units = 0;
+        fill_ring = 0; fill_stream = 0; fill_chunks = 0;
+        constexpr int CHUNKS = M16_RING_UNITS / CHUNK;
+        for (int k = w; k < CHUNKS; k += RingBf16::WAVES) load_chunk(k * CHUNK, k * CHUNK);
+    }
+    // This wave's loads have landed (required before any barrier that publishes them).
+    static __device__ __forceinline__ void landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // LDS byte address, for this lane, of unit `rel` (a multiple of PIECE_UNITS) of the current segment.
+    __device__ __forceinline__ uint32_t piece_ptr(int rel) const {
+        return (uint32_t)(uintptr_t)(lds + wrap_ring(cons + rel) * UNIT_BYTES + lane * 16);
+    }
+    // Behind the closing barrier of this wave's run over a segment of U units: work out the refill
+    // duty of this wave's group, then move on.  Group 1: first half of the slot just left (group 0
+    // left it a phase ago).  Group 0: second half of the slot BEFORE it (group 1 is still reading
+    // the one just left).  Halves are cut at chunk boundaries; wave gw issues chunks gw, gw + 4, ...
+    // of its group's half through refill(round).
+    template <int U>
+    __device__ __forceinline__ void finish() {
+        static_assert(U % 8 == 0, "segments are whole pieces");
+        if (group) {
+            fill_chunks = (U / CHUNK + 1) / 2;
+            fill_ring = cons;
+            fill_stream = cons_stream + M16_RING_UNITS;
+        } else {
+            const uint32_t first = (prev_units / CHUNK + 1) / 2;       // chunks of the other group's half
+            fill_chunks = prev_units / CHUNK - first;
+            fill_ring = prev_cons + first * CHUNK;
+            fill_stream = prev_stream + M16_RING_UNITS + first * CHUNK;
+            prev_cons = cons; prev_stream = cons_stream; prev_units = U;
+        }
+        cons = wrap_ring(cons + U);
+        cons_stream = wrap_stream(cons_stream + U);
+    }
+    __device__ __forceinline__ void refill(uint32_t round) {
+        const uint32_t k = gw + 4 * round;
+        if (k < fill_chunks) load_chunk(fill_ring + k * CHUNK, fill_stream + k * CHUNK);
+    }
+};
 
 using Frag16 = bf16x8;
 struct Act16 { Frag16 f[M16_KU][2]; };          // one layer's activations: [k-unit][sample block]
@@ -63,74 +150,80 @@ enum { M16_ENC_NONE = 0, M16_ENC_STASH = 1, M16_ENC_REGS = 2 };
 // One Linear layer of NT 16-row output tiles on [encoder k-units | CK chained k-units].
 //   ENC: where the encoder segment's B operands come from (the wave's LDS stash, or `encr`)
 //   SIGMA: also accumulate the density head's dot product on the fp32 activations (per block)
+// Each group of four tiles is one ring segment and one phase: prepare, run (between its two
+// barriers), refill, convert.
 template <int ACT, int NT, int CK, bool SIGMA, int ENC>
-__device__ __forceinline__ void linear16(WeightRing<RingBf16>& ring, lds_floats_t bias, int q, const Act16& hin, Act16& hout,
+__device__ __forceinline__ void linear16(PhasedRing& ring, lds_floats_t bias, int q, const Act16& hin, Act16& hout,
                                          lds_floats_t sigw, float (&dot)[2], Stamps& st, uint32_t stash,
                                          const Frag16 (&encr)[M16_ENC_KU][2]) {
     using P = Prec<NERFX_PREC_BF16>;
     static_assert(NT % 4 == 0 && (CK == 0 || CK == M16_KU), "full groups of four tiles on 0 or 256 chained inputs");
-    static_assert(CK > 0 || ENC != M16_ENC_NONE, "a layer needs an input");
+    static_assert(CK > 0 || ENC == M16_ENC_STASH, "an encoder-only layer reads the stash");
+    constexpr int ENC_UNITS = ENC != M16_ENC_NONE ? 8 : 0, UNITS = ENC_UNITS + 4 * CK;
 #pragma unroll
     for (int grp = 0; grp < NT / 4; ++grp) {
         f32x4 c[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) c[t][0] = c[t][1] = NERFX_LDS_VEC(f32x4, bias + 16 * (grp * 4 + t) + 4 * q);
+        uint32_t p[UNITS / PIECE_UNITS];
+#pragma unroll
+        for (int k = 0; k < UNITS / PIECE_UNITS; ++k) p[k] = ring.piece_ptr(k * PIECE_UNITS);
+        const uint32_t lane16 = (uint32_t)ring.lane * 16u;
         Frag16 a0, a1, a2, a3;
-        if constexpr (ENC != M16_ENC_NONE) {
-            st.mark(ST_EPILOGUE);
-            ring.template acquire<1>();
-            st.mark(ST_ACQUIRE);
-            const uint32_t p0 = (uint32_t)(uintptr_t)ring.unit_ptr(0);
-            if constexpr (ENC == M16_ENC_STASH)
-                m16_run8_stash(c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1], c[3][0], c[3][1], p0, stash,
-                               (uint32_t)ring.lane * 16u);
-            else
-                m16_run8(c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1], c[3][0], c[3][1], a0, a1, a2, a3, p0,
-                         encr[0][0], encr[0][1], encr[1][0], encr[1][1]);
-            st.mark(ST_RUN);
-            ring.template release<1>();
+        st.mark(ST_EPILOGUE);
+        PhasedRing::landed();
+        st.mark(ST_ACQUIRE);
+        // (the wave inside a run goes first on its SIMD: its partner's VALU work takes the slots
+        // between the MFMAs)
+        __builtin_amdgcn_s_setprio(3);
+#define NERFX_C c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1], c[3][0], c[3][1], a0, a1, a2, a3
+#define NERFX_B(k0) hin.f[k0][0], hin.f[k0][1], hin.f[k0 + 1][0], hin.f[k0 + 1][1], hin.f[k0 + 2][0], hin.f[k0 + 2][1], hin.f[k0 + 3][0], hin.f[k0 + 3][1]
+        if constexpr (CK == 0) {
+            m16_run8_stash_first_last(NERFX_C, p[0], stash, lane16);
+        } else {
+            constexpr int E = ENC_UNITS / PIECE_UNITS;                   // pieces in front of the chained ones
+            if constexpr (ENC == M16_ENC_STASH) m16_run8_stash_first_out(NERFX_C, p[0], p[1], stash, lane16);
+            if constexpr (ENC == M16_ENC_REGS) m16_run8_first_out(NERFX_C, p[0], p[1], encr[0][0], encr[0][1], encr[1][0], encr[1][1]);
+            if constexpr (ENC == M16_ENC_NONE) m16_run16_first_out(NERFX_C, p[0], p[1], p[2], NERFX_B(0));
+            else m16_run16_out(NERFX_C, p[E], p[E + 1], p[E + 2], NERFX_B(0));
+            m16_run16_last(NERFX_C, p[E + 2], p[E + 3], NERFX_B(4));
         }
-        if constexpr (CK == M16_KU) {
-            st.mark(ST_EPILOGUE);
-            ring.template acquire<4>();
-            st.mark(ST_ACQUIRE);
-            uint32_t p[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) p[k] = (uint32_t)(uintptr_t)ring.unit_ptr(k * PIECE_UNITS);
-            // (the wave inside a hand-scheduled run goes first on its SIMD, as in mlp_fwd_impl.hpp)
-            __builtin_amdgcn_s_setprio(3);
-            m16_run16_out(c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1], c[3][0], c[3][1], a0, a1, a2, a3, p[0], p[1], p[2],
-                          hin.f[0][0], hin.f[0][1], hin.f[1][0], hin.f[1][1], hin.f[2][0], hin.f[2][1], hin.f[3][0], hin.f[3][1]);
-            m16_run16_in(c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1], c[3][0], c[3][1], a0, a1, a2, a3, p[2], p[3],
-                         hin.f[4][0], hin.f[4][1], hin.f[5][0], hin.f[5][1], hin.f[6][0], hin.f[6][1], hin.f[7][0], hin.f[7][1]);
-            __builtin_amdgcn_s_setprio(0);
-            st.mark(ST_RUN);
-            ring.template release<4>();
-        }
-        // epilogue: activation, density dot, conversion to the next layer's operands
+#undef NERFX_C
+#undef NERFX_B
+        __builtin_amdgcn_s_setprio(0);
+        st.mark(ST_RUN);
+        ring.template finish<UNITS>();
+        // epilogue: activation, density dot, conversion to the next layer's operands, with this
+        // wave's refill loads spread between its four quarters
         constexpr bool packed_relu = ACT == NERFX_ACT_RELU && !SIGMA;
-        if constexpr (!packed_relu) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+            if (t == 0) ring.refill(0);
+            if (t == 2) ring.refill(1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!packed_relu) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) c[t][s][r] = activate<NERFX_PREC_BF16, ACT>(c[t][s][r]);
-        }
-        if constexpr (SIGMA) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            }
+            if constexpr (SIGMA) {
                 const f32x4 w = NERFX_LDS_VEC(f32x4, sigw + 16 * (grp * 4 + t) + 4 * q);
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dot[s] = fmaf(c[t][s][r], w[r], dot[s]);
+                // pin the sums here: hipcc otherwise sinks the whole chain (and with it the live fp32
+                // activations) below the refill's branches, towards the density head
+                asm volatile("" : "+v"(dot[0]), "+v"(dot[1]));
             }
+            if (t & 1) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) hout.f[grp * 2 + t / 2][s] = m16_from_acc<packed_relu>(c[t - 1][s], c[t][s]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) hout.f[grp * 2 + j][s] = m16_from_acc<packed_relu>(c[2 * j][s], c[2 * j + 1][s]);
+        st.mark(ST_HEADS);
     }
 }
 
@@ -147,10 +240,12 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
     // LDS: [const block | per-wave encoding stash | weight ring]
     const lds_bytes_t stash_base = (lds_bytes_t)smem + a.const_floats * (int)sizeof(float);
     const lds_bytes_t my_stash = stash_base + wave * M16_STASH_BYTES_PER_WAVE + lane * 16;
-    WeightRing<RG> ring;
-    ring.init(a.stream, stash_base + WAVES * M16_STASH_BYTES_PER_WAVE, a.n_pieces, wave, lane);
+    PhasedRing ring;
+    ring.init(a.stream, stash_base + WAVES * M16_STASH_BYTES_PER_WAVE, a.n_pieces * PIECE_UNITS, wave, lane);
     for (int i = tid; i < a.const_floats; i += 64 * WAVES) cst[i] = a.consts[i];
+    PhasedRing::landed();                                           // this wave's share of the initial fill
     __syncthreads();
+    if (ring.group == 1) __builtin_amdgcn_s_barrier();              // half a step behind group 0, from here on
 
     const lds_floats_t sigw = cst + a.sigw_off;
     const bool colour = a.rgb != nullptr;
@@ -248,18 +343,21 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
             // ---- rgb.2 (one 16-row tile on 128 inputs: 4 units in one piece) + widened sigmoid
             // (model.py:54, activations.py:18-20)
             st.mark(ST_EPILOGUE);
-            ring.template acquire<1>();
-            st.mark(ST_ACQUIRE);
             f32x4 out[2];
             out[0] = out[1] = NERFX_LDS_VEC(f32x4, cst + li * BIAS_STRIDE + 4 * q);
+            const lds_bytes_t w0 = (lds_bytes_t)(uintptr_t)ring.piece_ptr(0);
+            PhasedRing::landed();
+            __builtin_amdgcn_s_barrier();                           // this segment's phase: compiler-scheduled, 8 MFMAs
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const Frag16 w = NERFX_LDS_VEC(bf16x8, ring.unit_ptr(k));
+                const Frag16 w = NERFX_LDS_VEC(bf16x8, w0 + k * UNIT_BYTES);
                 out[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, B.f[k][0], out[0], 0, 0, 0);
                 out[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, B.f[k][1], out[1], 0, 0, 0);
             }
+            __builtin_amdgcn_s_barrier();
             st.mark(ST_RUN);
-            ring.template release<1>();
+            ring.template finish<8>();
+            ring.refill(0);
             if (q == 0) {                                           // rows 0..2 of the tile sit in lane group 0
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -275,17 +373,19 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
         }
         st.mark(ST_HEADS);
     }
+    if (ring.group == 0) __builtin_amdgcn_s_barrier();              // pairs with group 1's last closing barrier
     st.flush(a.stamps, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // no LDS-DMA may outlive the workgroup
 }
 
 template <int ACT, int HD>
 static int launch_cfg16(const MlpArgs& a, hipStream_t stream) {
     using RG = RingBf16;
     auto kern = mlp_fwd16_kernel<ACT, HD>;
-    const size_t lds_bytes = (size_t)a.const_floats * sizeof(float) + (size_t)RG::PIECES * PIECE_UNITS * UNIT_BYTES +
+    const size_t lds_bytes = (size_t)a.const_floats * sizeof(float) + (size_t)M16_RING_UNITS * UNIT_BYTES +
                              (size_t)RG::WAVES * M16_STASH_BYTES_PER_WAVE;
     NERFX_REQUIRE(lds_bytes <= 160 * 1024, "model needs %zu bytes of LDS per workgroup", lds_bytes);
+    NERFX_REQUIRE(a.n_pieces * PIECE_UNITS >= 2u * M16_RING_UNITS, "stream shorter than two ring lengths");
     static thread_local size_t configured = 0;
     if (lds_bytes > configured) {
         NERFX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -13,7 +13,7 @@ model = NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 6), 256, 4).cuda()
 h = ops.handle_for(model)
 B = 65536
 ro, rd = torch.rand(B, 3, device="cuda"), torch.rand(B, 3, device="cuda")
-names = ["prologue", "acquire", "mfma runs", "epilogue", "heads", "encode"]
+names = ["prologue", "acquire (wait for own loads)", "mfma runs incl. both barriers", "epilogue + next run set-up", "heads / refill issue", "encode"]
 for n, dens in ((64, True), (128, False)):
     t = torch.rand(B, n, device="cuda") * 4 + 2
     for prec in (1,):
