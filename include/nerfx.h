@@ -285,6 +285,11 @@ int nerfx_distill_loss(const float* t_sigma, const float* t_rgb, const float* s_
  * add per-phase cycle counts (6 x uint64: prologue, ring hand-over, MFMA runs, epilogue,
  * heads, encode) into `device_buffer`; NULL switches it off.  A regular build ignores it. */
 void nerfx_debug_set_stamps(unsigned long long* device_buffer);
+/* No counterpart in the reference.  bf16 inference of 129..256-wide skip models of depth 4 or 8
+ * runs on a kernel built on v_mfma_f32_16x16x32_bf16; enable = 0 keeps it on the general
+ * v_mfma_f32_32x32x16_bf16 kernels instead (same arithmetic, other summation order), for A/B
+ * timing and for tests that hold one kernel against the other.  Process-wide; default on. */
+void nerfx_debug_set_m16(int enable);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,5 @@
 // K2 entry points: validate, fill the launch arguments from the model plan, dispatch.
+#include <atomic>
 #include <cstdlib>
 
 #include "mlp_bwd_impl.hpp"
@@ -29,11 +30,20 @@ using namespace nerfx;
 static unsigned long long* g_stamps = nullptr;
 extern "C" void nerfx_debug_set_stamps(unsigned long long* device_buffer) { g_stamps = device_buffer; }
 
-// NERFX_NO_M16=1 in the environment keeps bf16 inference on the 32x32x16 kernels (A/B timing).
+// Diagnostic switch: bf16 inference of the models the 16x16x32 kernel takes can be kept on the
+// 32x32x16 kernels (A/B timing, and tests that hold one kernel against the other).  Starts from
+// NERFX_NO_M16=1 in the environment.
+static std::atomic<int> g_m16{-1};
 static bool m16_enabled() {
-    static const bool on = [] { const char* e = getenv("NERFX_NO_M16"); return !(e && e[0] == '1'); }();
-    return on;
+    int v = g_m16.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("NERFX_NO_M16");
+        v = !(e && e[0] == '1');
+        g_m16.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
 }
+extern "C" void nerfx_debug_set_m16(int enable) { g_m16.store(enable ? 1 : 0, std::memory_order_relaxed); }
 
 static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0, const float* p1, const float* t,
                       int64_t n_points, int n_samples, float* sigma, float* rgb, void* stream, void* tape = nullptr,

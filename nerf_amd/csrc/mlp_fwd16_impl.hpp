@@ -358,6 +358,7 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
             st.mark(ST_RUN);
             ring.template finish<8>();
             ring.refill(0);
+            ring.refill(1);                                         // (group 0's duty here is half of rgb.0's last slot: 5 chunks)
             if (q == 0) {                                           // rows 0..2 of the tile sit in lane group 0
 #pragma unroll
                 for (int s = 0; s < 2; ++s)

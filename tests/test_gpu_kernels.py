@@ -564,3 +564,36 @@ def test_bf16_density_head_keeps_tiny_densities(ops):
     ops.set_precision(None)
     assert_close(w[:, -1].cpu(), w_ref[:, -1], rtol=0, atol=1e-3, what="last-sample weight (bf16)")
     assert_close(rgb.cpu(), rgb_ref, rtol=0, atol=1e-2, what="rgb (bf16)")
+
+
+@pytest.mark.parametrize("name", ["g3_mlp_base", "g3_mlp_readme"])
+def test_bf16_kernels_agree_with_each_other(ops, name):
+    """The 16x16x32-MFMA inference kernel against the general 32x32x16 one on the same bf16
+    operands: they differ in summation order only, so they must agree far inside the 1e-2 bar --
+    a weight unit read from the wrong place of the ring (or a stale one) would not.  Several
+    blocks per workgroup, ragged tail, density-only and full passes."""
+    from nerf_amd import _lib
+    meta, g = load_golden(name)
+    model = product_model(meta, g)
+    h = ops.handle_for(model)
+    gen = torch.Generator().manual_seed(17)
+    M = 256 * 256 * 5 + 77                                       # five blocks per CU and a ragged one
+    x = ((torch.rand(M, 3, generator=gen) * 2 - 1) * 3).cuda()
+    d = (torch.rand(M, 3, generator=gen) * 2 - 1).cuda()
+    out = {}
+    try:
+        for m16 in (1, 0):
+            _lib.lib.nerfx_debug_set_m16(m16)
+            s_full, c_full = ops.mlp_points(h, x, d, prec=_lib.PREC_BF16)
+            s_dens, _ = ops.mlp_points(h, x, d, density_only=True, prec=_lib.PREC_BF16)
+            again, _ = ops.mlp_points(h, x, d, density_only=True, prec=_lib.PREC_BF16)
+            assert torch.equal(s_dens, again), "run-to-run difference"
+            assert torch.equal(s_full, s_dens), "density differs between the full and the density-only pass"
+            out[m16] = (s_full, c_full)
+    finally:
+        _lib.lib.nerfx_debug_set_m16(1)
+    assert_close(out[1][0].cpu(), out[0][0].cpu(), rtol=2e-3, atol=2e-4, what="sigma: 16x16x32 kernel vs 32x32x16 kernel")
+    assert_close(out[1][1].cpu(), out[0][1].cpu(), rtol=0, atol=5e-4, what="rgb: 16x16x32 kernel vs 32x32x16 kernel")
+    # and a part of the batch alone gives the same bits as inside the whole
+    part, _ = ops.mlp_points(h, x[256 * 700:256 * 900 + 13], d[256 * 700:256 * 900 + 13], density_only=True, prec=_lib.PREC_BF16)
+    assert torch.equal(part, out[1][0][256 * 700:256 * 900 + 13])
