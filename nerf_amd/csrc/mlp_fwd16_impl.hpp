@@ -111,6 +111,9 @@ struct PhasedRing {
         cons_stream = wrap_stream(cons_stream + U);
     }
     __device__ __forceinline__ void refill(uint32_t round) {
+#ifdef NERFX_DIAG_NO_REFILL                      // timing diagnostic (wrong results): what do the refill loads cost?
+        return;
+#endif
         const uint32_t k = gw + 4 * round;
         if (k < fill_chunks) load_chunk(fill_ring + k * CHUNK, fill_stream + k * CHUNK);
     }
@@ -169,14 +172,14 @@ __device__ __forceinline__ void linear16(PhasedRing& ring, lds_floats_t bias, in
 #pragma unroll
         for (int k = 0; k < UNITS / PIECE_UNITS; ++k) p[k] = ring.piece_ptr(k * PIECE_UNITS);
         const uint32_t lane16 = (uint32_t)ring.lane * 16u;
-        Frag16 a0, a1, a2, a3;
+        Frag16 a[M16_LOOKAHEAD];
         st.mark(ST_EPILOGUE);
         PhasedRing::landed();
         st.mark(ST_ACQUIRE);
         // (the wave inside a run goes first on its SIMD: its partner's VALU work takes the slots
         // between the MFMAs)
         __builtin_amdgcn_s_setprio(3);
-#define NERFX_C c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1], c[3][0], c[3][1], a0, a1, a2, a3
+#define NERFX_C c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1], c[3][0], c[3][1], M16_A_ARGS(a)
 #define NERFX_B(k0) hin.f[k0][0], hin.f[k0][1], hin.f[k0 + 1][0], hin.f[k0 + 1][1], hin.f[k0 + 2][0], hin.f[k0 + 2][1], hin.f[k0 + 3][0], hin.f[k0 + 3][1]
         if constexpr (CK == 0) {
             m16_run8_stash_first_last(NERFX_C, p[0], stash, lane16);
@@ -217,10 +220,17 @@ __device__ __forceinline__ void linear16(PhasedRing& ring, lds_floats_t bias, in
                 // activations) below the refill's branches, towards the density head
                 asm volatile("" : "+v"(dot[0]), "+v"(dot[1]));
             }
+#ifdef NERFX_DIAG_NO_EPILOGUE                    // timing diagnostic (wrong results): what does the conversion cost?
+            if (t & 1) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) asm volatile("" : "=v"(hout.f[grp * 2 + t / 2][s]) : "v"(c[t - 1][s]), "v"(c[t][s]));
+            }
+#else
             if (t & 1) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) hout.f[grp * 2 + t / 2][s] = m16_from_acc<packed_relu>(c[t - 1][s], c[t][s]);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         st.mark(ST_HEADS);

@@ -91,3 +91,47 @@ class ScriptableField(torch.nn.Module):
         sigma = O.shifted_softplus(self.sigma(x)).view(-1)
         rgb = O.widened_sigmoid(self.rgb(torch.cat((pd, self.features(x)), dim=-1)))
         return sigma, rgb
+
+
+# ---- float64 truth (decides how far fp32 results may sit from a reference fixture) ---------
+class float64_default:
+    """Context: torch's default dtype is float64, so the oracle's linspace / full / constants are."""
+
+    def __enter__(self):
+        self.prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+
+    def __exit__(self, *exc):
+        torch.set_default_dtype(self.prev)
+
+
+def oracle_model_f64(meta, arrays, prefix=""):
+    """oracle_model with every parameter, encoder table and constant in float64: the same function
+    of the same fp32 inputs, evaluated ~1e9 times more finely than either fp32 implementation."""
+    params = {k: v.double() for k, v in O.synth_params(meta["e_x"], meta["e_d"], meta["width"], meta["depth"],
+                                                       meta["resid"], meta["seed"]).items()}
+
+    def enc(spec, b):
+        if spec[0] == "pe":
+            with float64_default():
+                bands = O.positional_freq_bands(int(spec[1]))
+            # the reference's bands are fp32 numbers: keep those, not float64's own 2 ** linspace
+            bands = O.positional_freq_bands(int(spec[1])).double()
+            return O.make_encoder("pe", bands)
+        return O.make_encoder("ff", b.double())
+
+    return O.Model(params, enc(meta["enc_x"], arrays.get(prefix + "b_x")), enc(meta["enc_d"], arrays.get(prefix + "b_d")),
+                   meta["activ"], meta["resid"])
+
+
+def assert_no_farther_than_reference(got, fixture, truth, what, factor=2.0, floor=0.0):
+    """max |got - truth| <= factor * max |fixture - truth| (+ floor): the HIP result may sit at
+    most `factor` times as far from the float64 evaluation as the reference's own fp32 result.
+    Returns (our error, the reference's error)."""
+    got, fixture, truth = (torch.as_tensor(x).double() for x in (got, fixture, truth))
+    assert got.shape == truth.shape == fixture.shape, f"{what}: shapes {got.shape} {fixture.shape} {truth.shape}"
+    ours = float((got - truth).abs().max())
+    theirs = float((fixture - truth).abs().max())
+    assert ours <= factor * theirs + floor, (f"{what}: max |hip - f64| = {ours:.3e} but the reference's own fp32 result is "
+                                            f"only {theirs:.3e} from f64 (allowed {factor:g}x + {floor:g})")
+    return ours, theirs

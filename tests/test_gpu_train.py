@@ -7,10 +7,12 @@ identical inputs.  For a whole training step the gradients are sums of 4096 samp
 cancel to ~1e-5, and torch's own fp32 CPU autograd (the reference) is then up to 2.3e-2 of
 a tensor's largest entry away from a float64 evaluation of the same function; the kernels
 are held to 1e-4 against that float64 evaluation and to 5e-2 against the reference's
-captured fp32 gradients.  bf16 gradients (no tolerance is stated for them anywhere): 15 % in
-the Frobenius norm and 25 % of the largest entry per element -- in a ReLU network the gates
-of pre-activations that lie within bf16 rounding of zero (about 1 % of them) flip, which alone
-is a ~10 % relative change of a layer's gradient; the SiLU model stays below 5 %.
+captured fp32 gradients.  bf16 gradients (no tolerance is stated for them anywhere): 14 % in
+the Frobenius norm and 18 % of the largest entry per element, 1.5 x the largest errors measured
+over all fixtures and tensors (9.5 % / 12.2 %, both on the first layers of the 256 x 4 ReLU
+model; run with NERFX_TEST_REPORT=1 and -s to print them) -- in a ReLU network the gates of
+pre-activations that lie within bf16 rounding of zero (about 1 % of them) flip, which alone is
+a ~10 % relative change of a layer's gradient; the SiLU model stays below 5 %.
 """
 import numpy as np
 import pytest
@@ -39,9 +41,12 @@ def assert_grad_close(got, want, frac, what):
     assert err <= frac * scale + 1e-12, f"{what}: max abs err {err:.3e} vs scale {scale:.3e} (allowed {frac:g} of it)"
 
 
-def assert_grad_close_bf16(got, want, what, l2=0.15, peak=0.25):
+def assert_grad_close_bf16(got, want, what, l2=0.14, peak=0.18):
     got, want = got.double(), want.double()
     rel = float((got - want).norm() / want.norm().clamp_min(1e-30))
+    import os
+    if os.environ.get("NERFX_TEST_REPORT"):
+        print(f"BF16GRAD {what}: frob {rel:.4f} peak {float((got - want).abs().max() / want.abs().max()):.4f}")
     assert rel <= l2, f"{what}: relative Frobenius error {rel:.3e} > {l2:g}"
     assert_grad_close(got, want, peak, what)
 
@@ -71,15 +76,14 @@ def test_mlp_backward_vs_oracle(ops, name, prec):
     assert sigma.requires_grad and rgb.requires_grad
     ((sigma * g_sigma.cuda()).sum() + (rgb * g_rgb.cuda()).sum()).backward()
     ops.set_precision(None)
-    fourier = meta["enc_x"][0] == "ff"
     if prec == "fp32":
-        rt, at = (2e-3, 2e-3) if fourier else (1e-5, 2e-6)
+        rt, at = 1e-5, 2e-6
         assert_close(sigma.detach().cpu(), want_s, rtol=rt, atol=at, what="sigma (training forward)")
         assert_close(rgb.detach().cpu(), want_c, rtol=rt, atol=at, what="rgb (training forward)")
     for k, p in model.named_parameters():
         assert p.grad is not None, f"{k} got no gradient"
         if prec == "fp32":
-            assert_grad_close(p.grad.cpu(), want[k], 5e-3 if fourier else 1e-4, f"{name} fp32 grad {k}")
+            assert_grad_close(p.grad.cpu(), want[k], 1e-4, f"{name} fp32 grad {k}")
         else:
             assert_grad_close_bf16(p.grad.cpu(), want[k], f"{name} bf16 grad {k}")
 

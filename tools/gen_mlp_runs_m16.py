@@ -20,7 +20,7 @@ takes at most 30 operands.
 
     python tools/gen_mlp_runs_m16.py > nerf_amd/csrc/mlp_runs_m16.inc
 """
-LOOKAHEAD = 4
+LOOKAHEAD = 4          # A operands in flight ahead of their MFMAs (units); 8 measured the same
 TILES = 4
 
 
@@ -129,6 +129,8 @@ print("// GENERATED by tools/gen_mlp_runs_m16.py -- do not edit.")
 print("// c<t><s>: accumulator of output tile t (16 rows), sample block s; a*: A operands in flight;")
 print("// p*: LDS byte address of each piece for this lane (pn: first piece of the next block);")
 print("// b<k><s>: B operand of k-unit k, block s.")
+print(f"#define M16_LOOKAHEAD {LOOKAHEAD}")
+print("#define M16_A_ARGS(a) " + ", ".join(f"a[{j}]" for j in range(LOOKAHEAD)))
 print(gen_run(8, True, False, stash_b=True))     # layer 0: encoder segment alone
 print(gen_run(8, True, True, stash_b=True))      # skip layer: encoder segment, chained segment follows
 print(gen_run(8, True, True))                    # rgb.0: encoder operands in registers, chained segment follows
