@@ -207,6 +207,40 @@ int nerfx_render_fwd(const nerfx_model_t* coarse, const nerfx_model_t* fine, int
                      void* workspace, int64_t workspace_bytes,
                      float* t, float* weights, float* depth_map, float* rgb_map, void* stream);
 
+/* Uniforms for perturb=True drawn inside the sampling kernels (the reference draws them from
+ * torch's global generator, ray.py:99, :167): Philox4x32-10 keyed by `seed`; element e of a
+ * draw is word e % 4 of counter block e / 4 at `offset`.  Two calls with the same (seed, offset)
+ * produce the same jitter; advance `offset` by at least one between calls.  Where a caller
+ * passes its own u_c / u_f arrays, those win (test mode). */
+typedef struct { uint64_t seed; uint64_t offset; } nerfx_rng_t;
+/* nerfx_render_fwd with the generator: `rng` (host, may be NULL = perturb off). */
+int nerfx_render_fwd_rng(const nerfx_model_t* coarse, const nerfx_model_t* fine, int precision,
+                         const float* ro, const float* rd, int64_t n_rays,
+                         float tn, float tf, int nc, int nf, const float* u_c, const float* u_f,
+                         const nerfx_rng_t* rng, void* workspace, int64_t workspace_bytes,
+                         float* t, float* weights, float* depth_map, float* rgb_map, void* stream);
+/* The uniforms of draw `which` (0: coarse stratification, 1: inverse-CDF positions; the voxel
+ * sampler uses 0..3) as the kernels see them: out[e], e < n.  For tests and for callers that want to replay a render. */
+int nerfx_rng_uniform(uint64_t seed, uint64_t offset, int which, int64_t n, float* out, void* stream);
+
+/* ---- training render: forward with tape, backward ----------------------------------------
+ * Replace render_volume(train=True) and autograd through it in the reference's training step
+ * (train.py:75-80; renderer.py:133-142): the coarse pass and the sample positions carry no
+ * gradient, the last pass (`fine`, or `coarse` when nf == 0) records its tape in `workspace`,
+ * and nerfx_render_bwd turns d loss / d rgb_map (B,3) [, d depth (B), d weights (B,n); NULL = 0]
+ * into d loss / d parameter of that model (`grads` as for nerfx_mlp_bwd).  `t` is the forward's
+ * output; the workspace must not be touched between the two calls. */
+int64_t nerfx_render_train_workspace_bytes(const nerfx_model_t* last, int precision, int64_t n_rays, int nc, int nf);
+int nerfx_render_train_fwd(const nerfx_model_t* coarse, const nerfx_model_t* fine, int precision,
+                           const float* ro, const float* rd, int64_t n_rays,
+                           float tn, float tf, int nc, int nf, const float* u_c, const float* u_f,
+                           const nerfx_rng_t* rng, void* workspace, int64_t workspace_bytes,
+                           float* t, float* weights, float* depth_map, float* rgb_map, void* stream);
+int nerfx_render_bwd(const nerfx_model_t* last, int precision, const float* rd, int64_t n_rays, int nc, int nf,
+                     const float* t, const float* g_rgb_map, const float* g_depth, const float* g_weights,
+                     void* workspace, int64_t workspace_bytes, float* const* grads /* host array */, int n_grads,
+                     void* stream);
+
 /* The same render for callers that cannot allocate device memory (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The
  * workspace is a static device array inside the library, NERFX_STATIC_WORKSPACE_BYTES per GPU,
@@ -279,6 +313,15 @@ int nerfx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int nerfx_distill_loss(const float* t_sigma, const float* t_rgb, const float* s_sigma, const float* s_rgb,
                        const float* delta, int64_t n, float* workspace, float* loss,
                        float* g_sigma, float* g_rgb, void* stream);
+
+/* A distillation batch (VoxelSampler.sample, distill.py:62-82) drawn on the device: `voxels` random
+ * cells of the voxels^3 grid whose centres are linspace(lo, hi, voxels) per axis, `samples` points
+ * per cell with normal jitter of half a cell (|hi - lo| / voxels / 2), directions uniform in
+ * [0,1)^3 then normalised, lengths uniform in [d0, d0 + |d1 - d0|).  Outputs rx, rd
+ * (voxels * samples, 3) and delta (voxels * samples).  Same generator as nerfx_rng_t. */
+int nerfx_voxel_sample(float x0, float x1, float y0, float y1, float z0, float z1, float d0, float d1,
+                       int voxels, int samples, uint64_t seed, uint64_t offset,
+                       float* rx, float* rd, float* delta, void* stream);
 
 /* ---- diagnostics --------------------------------------------------------------------
  * No counterpart in the reference.  In a library built with -DNERFX_STAMPS the MLP kernels

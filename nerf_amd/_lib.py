@@ -21,6 +21,10 @@ class ModelDesc(C.Structure):
                                          "width", "depth", "activ", "resid")]
 
 
+class Rng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
 class DeviceInfo(C.Structure):
     _fields_ = [("compute_units", C.c_int32), ("wavefront", C.c_int32),
                 ("lds_bytes_per_cu", C.c_int32), ("clock_khz", C.c_int32),
@@ -61,12 +65,20 @@ SIGNATURES = {
     "nerfx_gather_rays": (_i, [_p, _p, _p, _p, _l, _l, _l, _p, _p, _p, _p]),
     "nerfx_mse_loss": (_i, [_p, _p, _l, _p, _p, _p]),
     "nerfx_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
+    "nerfx_voxel_sample": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.c_uint64, C.c_uint64, _p, _p, _p, _p]),
     "nerfx_distill_loss": (_i, [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p]),
     "nerfx_debug_set_stamps": (None, [_p]),
     "nerfx_debug_set_m16": (None, [_i]),
     "nerfx_render_workspace_bytes": (_l, [_l, _i, _i]),
     "nerfx_render_fwd": (_i, [_p, _p, _i, _p, _p, _l, _f, _f, _i, _i, _p, _p, _p, _l,
                               _p, _p, _p, _p, _p]),
+    "nerfx_render_fwd_rng": (_i, [_p, _p, _i, _p, _p, _l, _f, _f, _i, _i, _p, _p, C.POINTER(Rng), _p, _l,
+                                  _p, _p, _p, _p, _p]),
+    "nerfx_rng_uniform": (_i, [C.c_uint64, C.c_uint64, _i, _l, _p, _p]),
+    "nerfx_render_train_workspace_bytes": (_l, [_p, _i, _l, _i, _i]),
+    "nerfx_render_train_fwd": (_i, [_p, _p, _i, _p, _p, _l, _f, _f, _i, _i, _p, _p, C.POINTER(Rng), _p, _l,
+                                    _p, _p, _p, _p, _p]),
+    "nerfx_render_bwd": (_i, [_p, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _l, C.POINTER(_p), _i, _p]),
     "nerfx_render_static_max_rays": (_l, [_i, _i]),
     "nerfx_render_fwd_static": (_i, [_p, _p, _i, _p, _p, _l, _f, _f, _i, _i, _p, _p,
                                      _p, _p, _p, _p, _p]),

@@ -32,8 +32,10 @@ class BoundedVolumeRaymarcher:
         """-> t (B,N), weights (B,N), depth_map (B,), rgb_map (B,3)
         (reference renderer.py:173-205).
 
-        `perturb` draws the stratification / inverse-CDF uniforms from torch's
-        generator of the rays' device, coarse first, as the reference does.
+        `perturb` draws the stratification / inverse-CDF uniforms inside the sampling
+        kernels (a Philox stream keyed by the seed and offset of torch's generator of the
+        rays' device, which the reference draws from: ray.py:99, :167), so no (B, N)
+        arrays of uniforms pass through memory; `torch.manual_seed` reproduces a render.
         With `train`, gradients reach the parameters of `fine` through the fine
         pass only (the coarse pass and the sample positions carry none), and the
         requires_grad flags of both modules are toggled exactly as in
@@ -41,14 +43,13 @@ class BoundedVolumeRaymarcher:
         autograd's state: every caller in the reference renders that way under
         inference_mode / no_grad (infer.py:13, train.py:71 for the val and test splits,
         bench.py:149); a caller that wants gradients passes train=True."""
-        B, nc, nf = ro.size(0), self.samples_c, self.samples_f
-        u_c = torch.rand((B, nc), device=ro.device) if perturb else None
-        u_f = torch.rand((B, nf), device=ro.device) if (perturb and nf > 0) else None
+        nc, nf = self.samples_c, self.samples_f
+        rng = ops.next_rng(ro.device) if (perturb and ro.is_cuda) else None
         if train:
             if nf > 0:
                 coarse.requires_grad(False)
-            return ops.render_train(coarse, fine if nf > 0 else coarse, ro, rd, self.tn, self.tf, nc, nf, u_c, u_f)
+            return ops.render_train(coarse, fine if nf > 0 else coarse, ro, rd, self.tn, self.tf, nc, nf, None, None, rng)
         with torch.no_grad():
             hc = ops.handle_for(coarse)
             hf = ops.handle_for(fine) if nf > 0 else None
-            return ops.render(hc, hf, ro, rd, self.tn, self.tf, nc, nf, u_c, u_f)
+            return ops.render(hc, hf, ro, rd, self.tn, self.tf, nc, nf, rng=rng)

@@ -5,6 +5,7 @@
 // ray.py:182-186, then the nc + nf values are put in ascending order (rank merge seeded by the
 // bin indices when the fine samples are already ascending, bitonic sort otherwise).
 #include "common.hpp"
+#include "philox.hpp"
 
 namespace nerfx {
 
@@ -58,7 +59,7 @@ __device__ __forceinline__ void wave_sync() {
 template <int R>
 __global__ __launch_bounds__(64) void pdf_sample_kernel(
     const float* __restrict__ t_c, const float* __restrict__ w_c, int64_t n_rays, int nc, int nf,
-    const float* __restrict__ u_g, float* __restrict__ t_sorted, float* __restrict__ cdf_out,
+    const float* __restrict__ u_g, Rng rng, float* __restrict__ t_sorted, float* __restrict__ cdf_out,
     int64_t* __restrict__ idx_out, float* __restrict__ t_pdf_out) {
     constexpr int ROW = 64 * R;
     __shared__ float tc[ROW], cdf[ROW], bins[ROW], tp[ROW], srt[2 * ROW];
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
         for (int q = 0; q < R; ++q) {
             const int j = lane + 64 * q;
             if (j >= nf) continue;
-            const float u = u_g ? u_cur[q] : linspace_at(0.f, 1.f, nf, j);
+            const float u = u_g ? u_cur[q] : (rng.on ? rng_uniform(rng, (uint64_t)(ray * nf + j)) : linspace_at(0.f, 1.f, nf, j));
             const int idx = upper_bound(cdf, nb, u);
             const int below = max(idx - 1, 0), above = min(idx, nw);
             const float cb = cdf[below], ca = cdf[above], bb = bins[below], ba = bins[above];
@@ -234,13 +235,9 @@ __global__ __launch_bounds__(256) void searchsorted_right_kernel(
     }
 }
 
-}  // namespace nerfx
-
-using namespace nerfx;
-
-extern "C" int nerfx_pdf_sample(const float* t_c, const float* w_c, int64_t n_rays, int nc, int nf,
-                                const float* u, float* t_sorted, float* cdf, int64_t* idx, float* t_pdf,
-                                void* stream) {
+// `u` = the caller's uniforms, else `rng.on` = draw them in the kernel, else linspace(0, 1, nf).
+int pdf_sample_launch(const float* t_c, const float* w_c, int64_t n_rays, int nc, int nf, const float* u, const Rng& rng,
+                      float* t_sorted, float* cdf, int64_t* idx, float* t_pdf, hipStream_t stream) {
     NERFX_REQUIRE(n_rays >= 0, "n_rays < 0");
     NERFX_REQUIRE(nc >= 3 && nc <= K4_MAX, "nc %d out of range [3, %d]", nc, K4_MAX);
     NERFX_REQUIRE(nf >= 1 && nf <= K4_MAX, "nf %d out of range [1, %d]", nf, K4_MAX);
@@ -249,9 +246,18 @@ extern "C" int nerfx_pdf_sample(const float* t_c, const float* w_c, int64_t n_ra
     const int grid = (int)std::min<int64_t>(n_rays, 256 * 32);
     const int longest = std::max(nc, nf);
     auto kern = longest <= 64 ? pdf_sample_kernel<1> : (longest <= 128 ? pdf_sample_kernel<2> : pdf_sample_kernel<4>);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, (hipStream_t)stream, t_c, w_c, n_rays, nc, nf, u, t_sorted,
-                       cdf, idx, t_pdf);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, stream, t_c, w_c, n_rays, nc, nf, u, rng, t_sorted, cdf, idx, t_pdf);
     return launch_status("pdf_sample_kernel");
+}
+
+}  // namespace nerfx
+
+using namespace nerfx;
+
+extern "C" int nerfx_pdf_sample(const float* t_c, const float* w_c, int64_t n_rays, int nc, int nf,
+                                const float* u, float* t_sorted, float* cdf, int64_t* idx, float* t_pdf,
+                                void* stream) {
+    return pdf_sample_launch(t_c, w_c, n_rays, nc, nf, u, Rng{}, t_sorted, cdf, idx, t_pdf, (hipStream_t)stream);
 }
 
 extern "C" int nerfx_searchsorted_right(const float* cdf, const float* u, int64_t n_rows, int n_cdf,

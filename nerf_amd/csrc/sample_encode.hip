@@ -5,6 +5,7 @@
 // then streamed to HBM with full-width coalesced stores: the kernel is bound by
 // the 4*(n*Ex) bytes per ray it writes, not by the transcendental math.
 #include "common.hpp"
+#include "philox.hpp"
 
 namespace nerfx {
 
@@ -85,18 +86,21 @@ __global__ __launch_bounds__(K1_THREADS) void sample_encode_kernel(
 // The form the render path launches: z values (and optionally segment lengths) only, one
 // thread per sample, so a wavefront writes 256 contiguous bytes per output.  The neighbour's z
 // value is recomputed rather than exchanged.
+// `u` = the caller's uniforms, else `rng.on` = draw them here, else no jitter.
 __global__ __launch_bounds__(256) void sample_t_kernel(const float* __restrict__ rd, int64_t n_rays, float tn, float tf,
-                                                       int n, const float* __restrict__ u, float* __restrict__ t_out,
+                                                       int n, const float* __restrict__ u, Rng rng, float* __restrict__ t_out,
                                                        float* __restrict__ delta_out) {
     const int64_t total = n_rays * n;
+    const bool jitter = u || rng.on;
+    auto uni = [&](int64_t e) { return u ? u[e] : rng_uniform(rng, (uint64_t)e); };
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
         const int64_t ray = q / n;
         const int i = (int)(q - ray * n);
-        const float t = u ? stratified_at(tn, tf, n, i, u[q]) : linspace_at(tn, tf, n, i);
+        const float t = jitter ? stratified_at(tn, tf, n, i, uni(q)) : linspace_at(tn, tf, n, i);
         if (t_out) t_out[q] = t;
         if (delta_out) {                                               // ray.py:62-65
             float d = 1e10f;
-            if (i + 1 < n) d = __fsub_rn(u ? stratified_at(tn, tf, n, i + 1, u[q + 1]) : linspace_at(tn, tf, n, i + 1), t);
+            if (i + 1 < n) d = __fsub_rn(jitter ? stratified_at(tn, tf, n, i + 1, uni(q + 1)) : linspace_at(tn, tf, n, i + 1), t);
             delta_out[q] = __fmul_rn(d, norm3(rd[3 * ray], rd[3 * ray + 1], rd[3 * ray + 2]));
         }
     }
@@ -105,8 +109,9 @@ __global__ __launch_bounds__(256) void sample_t_kernel(const float* __restrict__
 // The same for sample counts that are multiples of four (up to 1024): a thread owns four
 // consecutive samples of one ray and keeps its sample slot while it walks over rays, so the
 // index arithmetic is one 32-bit division per thread and every store is 128 bits wide.
+// With the generator, a thread's four samples are exactly one Philox block.
 __global__ __launch_bounds__(256) void sample_t4_kernel(const float* __restrict__ rd, int64_t n_rays, float tn, float tf,
-                                                        int n, const float* __restrict__ u, float* __restrict__ t_out,
+                                                        int n, const float* __restrict__ u, Rng rng, float* __restrict__ t_out,
                                                         float* __restrict__ delta_out) {
     const int tpr = n >> 2, rpb = 256 / tpr;                           // threads per ray, rays per workgroup pass
     const int slot = (int)threadIdx.x / tpr, i0 = ((int)threadIdx.x - slot * tpr) * 4;
@@ -124,6 +129,11 @@ __global__ __launch_bounds__(256) void sample_t4_kernel(const float* __restrict_
             t[2] = stratified_at(tn, tf, n, i0 + 2, uv.z);
             t[3] = stratified_at(tn, tf, n, i0 + 3, uv.w);
             t[4] = i0 + 4 < n ? stratified_at(tn, tf, n, i0 + 4, u[q + 4]) : 0.0f;
+        } else if (rng.on) {
+            const Philox4 b = rng_block(rng, (uint64_t)q >> 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = stratified_at(tn, tf, n, i0 + e, rng_to_float(b.w[e]));
+            t[4] = (delta_out && i0 + 4 < n) ? stratified_at(tn, tf, n, i0 + 4, rng_uniform(rng, (uint64_t)q + 4)) : 0.0f;
         } else {
 #pragma unroll
             for (int e = 0; e < 5; ++e) t[e] = lin[e];
@@ -168,6 +178,25 @@ static int check_encoder(int kind, int n, const float* table, const char* which)
     return 0;
 }
 
+__global__ __launch_bounds__(256) void rng_uniform_kernel(Rng rng, int64_t n, float* __restrict__ out) {
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (int64_t)gridDim.x * 256) out[q] = rng_uniform(rng, (uint64_t)q);
+}
+
+// t (and optionally delta) for n_rays x n_samples: the form the render paths launch.
+int sample_t_launch(const float* rd, int64_t n_rays, float tn, float tf, int n_samples, const float* u, const Rng& rng,
+                    float* t, float* delta, hipStream_t stream) {
+    const bool aligned = (((uintptr_t)t | (uintptr_t)delta | (uintptr_t)u) & 15) == 0;
+    if (n_samples % 4 == 0 && aligned) {
+        const int rpb = 256 / (n_samples / 4);
+        const int grid4 = (int)std::min<int64_t>((n_rays + rpb - 1) / rpb, 256 * 16);
+        hipLaunchKernelGGL(sample_t4_kernel, dim3(grid4), dim3(256), 0, stream, rd, n_rays, tn, tf, n_samples, u, rng, t, delta);
+        return launch_status("sample_t4_kernel");
+    }
+    const int grid = (int)std::min<int64_t>((n_rays * n_samples + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(sample_t_kernel, dim3(grid), dim3(256), 0, stream, rd, n_rays, tn, tf, n_samples, u, rng, t, delta);
+    return launch_status("sample_t_kernel");
+}
+
 }  // namespace nerfx
 
 using namespace nerfx;
@@ -185,20 +214,7 @@ extern "C" int nerfx_sample_encode_fwd(const float* ro, const float* rd, int64_t
     NERFX_REQUIRE(ro && rd, "ro / rd is NULL");
     if (phi_x) { int e = check_encoder(kx, nx, tx, "phi_x"); if (e) return e; }
     if (phi_d) { int e = check_encoder(kd, nd, td, "phi_d"); if (e) return e; }
-    if (!rx && !phi_x && !phi_d) {
-        const bool aligned = (((uintptr_t)t | (uintptr_t)delta | (uintptr_t)u) & 15) == 0;
-        if (n_samples % 4 == 0 && aligned) {
-            const int rpb = 256 / (n_samples / 4);
-            const int grid4 = (int)std::min<int64_t>((n_rays + rpb - 1) / rpb, 256 * 16);
-            hipLaunchKernelGGL(sample_t4_kernel, dim3(grid4), dim3(256), 0, (hipStream_t)stream, rd, n_rays, tn, tf,
-                               n_samples, u, t, delta);
-            return launch_status("sample_t4_kernel");
-        }
-        const int grid = (int)std::min<int64_t>((n_rays * n_samples + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(sample_t_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rd, n_rays, tn, tf, n_samples, u,
-                           t, delta);
-        return launch_status("sample_t_kernel");
-    }
+    if (!rx && !phi_x && !phi_d) return sample_t_launch(rd, n_rays, tn, tf, n_samples, u, Rng{}, t, delta, (hipStream_t)stream);
     const int grid = (int)std::min<int64_t>(n_rays, 256 * 16);
     hipLaunchKernelGGL(sample_encode_kernel, dim3(grid), dim3(K1_THREADS), 0, (hipStream_t)stream, ro, rd,
                        n_rays, tn, tf, n_samples, u, kx, nx, tx, kd, nd, td, t, delta, rx, phi_x, phi_d);
@@ -216,4 +232,13 @@ extern "C" int nerfx_encode_fwd(const float* v, int64_t n_points, int kind, int 
     hipLaunchKernelGGL(encode_points_kernel, dim3(grid), dim3(K1_THREADS), 0, (hipStream_t)stream, v,
                        n_points, kind, n, table, phi);
     return launch_status("encode_points_kernel");
+}
+
+extern "C" int nerfx_rng_uniform(uint64_t seed, uint64_t offset, int which, int64_t n, float* out, void* stream) {
+    NERFX_REQUIRE(n >= 0 && which >= 0 && which < 256, "bad size or draw index");
+    if (n == 0) return 0;
+    NERFX_REQUIRE(out != nullptr, "out is NULL");
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(rng_uniform_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, Rng{seed, offset, (uint32_t)which, 1}, n, out);
+    return launch_status("rng_uniform_kernel");
 }

@@ -2,6 +2,7 @@
 // MSE loss with its PSNR and gradient seed, and the Adam update with the loss scaler's inf check.
 // Small, bandwidth-bound kernels whose point is that nothing in a step waits for the host.
 #include "common.hpp"
+#include "philox.hpp"
 
 namespace nerfx {
 
@@ -82,9 +83,64 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ para
     }
 }
 
+// Distillation batches (distill.py:62-82): `voxels` random cells of a regular voxels^3 grid over
+// the domain, `samples` points per cell jittered around its centre with a normal of half a cell,
+// random directions (uniform in [0,1)^3, normalised) and segment lengths uniform in [d0, d0 + |d1 - d0|).
+// Point e draws: cell index = floor(u * voxels^3) of draw 0 element e / samples; three normals by
+// Box-Muller from draw 1 elements 6 e .. 6 e + 5; direction from draw 2 elements 3 e .. 3 e + 2;
+// length from draw 3 element e.
+__global__ __launch_bounds__(256) void voxel_sample_kernel(float x0, float x1, float y0, float y1, float z0, float z1,
+                                                           float d0, float d1, int voxels, int samples, Rng rng,
+                                                           float* __restrict__ rx, float* __restrict__ rd,
+                                                           float* __restrict__ delta) {
+    const int64_t n = (int64_t)voxels * samples;
+    const float lo[3] = {x0, y0, z0}, hi[3] = {x1, y1, z1};
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        Rng g = rng;
+        g.which = 0;
+        const uint32_t cells = (uint32_t)voxels * voxels * voxels;
+        uint32_t cell = (uint32_t)(rng_uniform(g, (uint64_t)(e / samples)) * (float)cells);
+        cell = cell < cells ? cell : cells - 1;
+        const int idx[3] = {(int)(cell / ((uint32_t)voxels * voxels)), (int)(cell / voxels % voxels), (int)(cell % voxels)};
+        g.which = 1;
+        const Philox4 a = rng_block(g, (uint64_t)(6 * e) >> 2), b = rng_block(g, ((uint64_t)(6 * e) >> 2) + 1);
+        const uint32_t w[8] = {a.w[0], a.w[1], a.w[2], a.w[3], b.w[0], b.w[1], b.w[2], b.w[3]};
+        const int o = (int)((6 * e) & 3);                           // 6 e is even: the six words start at 0 or 2
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float u1 = rng_to_float(w[o + 2 * c]), u2 = rng_to_float(w[o + 2 * c + 1]);
+            const float normal = sqrtf(-2.0f * logf(1.0f - u1)) * cosf(6.283185307179586f * u2);
+            const float centre = linspace_at(lo[c], hi[c], voxels, idx[c]);
+            const float half_cell = 0.5f * (fabsf(hi[c] - lo[c]) / (float)voxels);
+            rx[3 * e + c] = fmaf(normal, half_cell, centre);
+        }
+        g.which = 2;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = rng_uniform(g, (uint64_t)(3 * e + c));
+        const float len = norm3(v[0], v[1], v[2]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rd[3 * e + c] = v[c] / len;
+        g.which = 3;
+        delta[e] = fmaf(fabsf(d1 - d0), rng_uniform(g, (uint64_t)e), d0);
+    }
+}
+
 }  // namespace nerfx
 
 using namespace nerfx;
+
+extern "C" int nerfx_voxel_sample(float x0, float x1, float y0, float y1, float z0, float z1, float d0, float d1,
+                                  int voxels, int samples, uint64_t seed, uint64_t offset, float* rx, float* rd,
+                                  float* delta, void* stream) {
+    NERFX_REQUIRE(voxels >= 1 && voxels <= 256 && samples >= 1, "voxels %d (1..256) / samples %d out of range", voxels, samples);
+    NERFX_REQUIRE(rx && rd && delta, "an output is NULL");
+    const int64_t n = (int64_t)voxels * samples;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(voxel_sample_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x0, x1, y0, y1, z0, z1, d0, d1,
+                       voxels, samples, Rng{seed, offset, 0, 1}, rx, rd, delta);
+    return launch_status("voxel_sample_kernel");
+}
 
 extern "C" int nerfx_gather_rays(const float* C, const float* ro, const float* rd, const int64_t* perm,
                                  int64_t begin, int64_t n, int64_t n_total, float* C_out, float* ro_out,

@@ -32,32 +32,35 @@ class Domain(NamedTuple):
 
 
 class VoxelSampler:
-    """Random voxels of a regular grid, jittered samples inside them, random unit-ish directions
-    and segment lengths (reference distill.py:30-82).  Everything lives on `device`."""
+    """Batches of query points for distillation (reference distill.py:30-82): `voxels` random cells
+    of a regular voxels^3 grid over the domain, `samples` jittered points in each, random
+    directions and segment lengths.  Attributes as in the reference (`domain`, `voxels`, `samples`,
+    `batch_size`, `voxel_size`, `rx` = the grid's cell centres, len() = their number); `sample()`
+    is one launch of the sampling kernel on `device`, drawing from torch's generator of that device."""
 
     def __init__(self, domain: Domain, voxels: int, samples: int, device=None) -> None:
         self.domain, self.voxels, self.samples = domain, voxels, samples
         self.batch_size = voxels * samples
         self.device = torch.device("cuda" if device is None else device)
-        self.voxel_size = torch.tensor([abs(domain.x[1] - domain.x[0]), abs(domain.y[1] - domain.y[0]),
-                                        abs(domain.z[1] - domain.z[0])], dtype=torch.float32,
-                                       device=self.device) / voxels
-        axis = lambda d: torch.linspace(*d, steps=voxels, dtype=torch.float32, device=self.device)
-        self.rx = torch.cartesian_prod(axis(domain.x), axis(domain.y), axis(domain.z))
+        extent = [abs(hi - lo) for lo, hi in (domain.x, domain.y, domain.z)]
+        self.voxel_size = torch.tensor(extent, dtype=torch.float32, device=self.device) / voxels
+        self._centres = None
+
+    @property
+    def rx(self) -> Tensor:
+        """(voxels^3, 3) cell centres, x slowest; built on first use (the kernel does not read it)."""
+        if self._centres is None:
+            axes = [torch.linspace(lo, hi, steps=self.voxels, dtype=torch.float32, device=self.device)
+                    for lo, hi in (self.domain.x, self.domain.y, self.domain.z)]
+            self._centres = torch.cartesian_prod(*axes)
+        return self._centres
 
     def __len__(self) -> int:
-        return self.rx.size(0)
+        return self.voxels ** 3
 
     def sample(self) -> Tuple[Tensor, Tensor, Tensor]:
         """-> rx (B, 3), rd (B, 3), delta (B,) with B = voxels * samples."""
-        idxs = torch.randint(len(self), (self.voxels,), device=self.device)
-        rx = self.rx[idxs.repeat_interleave(self.samples, dim=0)]
-        rx = rx + torch.randn_like(rx) * (.5 * self.voxel_size[None, :])
-        rd = torch.rand((self.batch_size, 3), dtype=torch.float32, device=self.device)
-        rd = rd / torch.linalg.norm(rd, dim=-1, keepdim=True)
-        delta = torch.rand((self.batch_size,), dtype=torch.float32, device=self.device)
-        delta = self.domain.d[0] + abs(self.domain.d[1] - self.domain.d[0]) * delta
-        return rx, rd, delta
+        return ops.voxel_sample(self.domain, self.voxels, self.samples, self.device)
 
 
 def distill(teacher: NeRF, student: NeRF, sampler: VoxelSampler, optim: Optimizer, scheduler: Scheduler, scaler,

@@ -330,14 +330,39 @@ def _render_staged(coarse, fine, ro, rd, tn, tf, nc, nf, u_c, u_f, prec, log):
     return t, w, depth, rgb_map
 
 
+def next_rng(device) -> "_lib.Rng":
+    """A fresh (seed, offset) for one render's in-kernel uniforms, taken from torch's generator of
+    `device` -- the generator the reference's rand_like / rand draw from (ray.py:99, :167) -- whose
+    offset is advanced, so torch.manual_seed makes perturbed renders reproducible and every call
+    (and every rank seeded with distributed.seed_ranks) gets its own jitter."""
+    dev = torch.device(device)
+    gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+    offset = gen.get_offset()
+    gen.set_offset(offset + 4)
+    return _lib.Rng(gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, offset)
+
+
+def rng_uniform(rng, which: int, n: int, device) -> Tensor:
+    """The uniforms the kernels draw for `rng` (draw 0: coarse stratification, 1: inverse CDF)."""
+    out = torch.empty((n,), device=device)
+    with torch.cuda.device(out.device):
+        check(lib.nerfx_rng_uniform(rng.seed, rng.offset, which, n, _p(out), _stream()))
+    return out
+
+
 def render(coarse: ModelHandle, fine: Optional[ModelHandle], ro: Tensor, rd: Tensor, tn: float, tf: float,
            nc: int, nf: int, u_c: Optional[Tensor] = None, u_f: Optional[Tensor] = None,
-           prec: Optional[int] = None):
+           prec: Optional[int] = None, rng=None):
+    """render_volume without a graph.  Jitter: `u_c` / `u_f` where given, else drawn in the kernels
+    when `rng` (see next_rng) is given, else none."""
     ro, rd = _dev(ro, "ro"), _dev(rd, "rd")
     B, n, dev = ro.shape[0], nc + nf, ro.device
     u_c = None if u_c is None else _dev(u_c, "u_c")
     u_f = None if u_f is None else _dev(u_f, "u_f")
     if PROFILE is not None:
+        if rng is not None:                                          # the staged path takes arrays: the same numbers
+            u_c = rng_uniform(rng, 0, B * nc, dev).view(B, nc) if u_c is None else u_c
+            u_f = rng_uniform(rng, 1, B * nf, dev).view(B, nf) if (u_f is None and nf > 0) else u_f
         return _render_staged(coarse, fine, ro, rd, tn, tf, nc, nf, u_c, u_f,
                               precision() if prec is None else prec, PROFILE)
     t = torch.empty((B, n), device=dev)
@@ -348,9 +373,10 @@ def render(coarse: ModelHandle, fine: Optional[ModelHandle], ro: Tensor, rd: Ten
     ws = torch.empty((max(ws_bytes, 1),), device=dev, dtype=torch.uint8)
     with torch.cuda.device(dev):
         prec = precision() if prec is None else prec
-        check(lib.nerfx_render_fwd(coarse.ready(prec), None if fine is None else fine.ready(prec),
-                                   prec, _p(ro), _p(rd), B, tn, tf, nc, nf,
-                                   _p(u_c), _p(u_f), _p(ws), ws_bytes, _p(t), _p(w), _p(depth), _p(rgb_map), _stream()))
+        check(lib.nerfx_render_fwd_rng(coarse.ready(prec), None if fine is None else fine.ready(prec),
+                                       prec, _p(ro), _p(rd), B, tn, tf, nc, nf, _p(u_c), _p(u_f),
+                                       None if rng is None else C.byref(rng), _p(ws), ws_bytes,
+                                       _p(t), _p(w), _p(depth), _p(rgb_map), _stream()))
     return t, w, depth, rgb_map
 
 
@@ -438,6 +464,57 @@ class _CompositeFunction(torch.autograd.Function):
         return g_sigma, g_rgb, None, None
 
 
+class _RenderTrainFunction(torch.autograd.Function):
+    """render_volume(train=True) as two C calls: nerfx_render_train_fwd records the last pass's tape,
+    nerfx_render_bwd turns (d weights, d depth, d rgb_map) into the parameter gradients of the
+    model that rendered the last pass.  t, ro, rd carry no gradient (reference renderer.py:133-135)."""
+
+    @staticmethod
+    def forward(ctx, hc, hl, prec, ro, rd, tn, tf, nc, nf, u_c, u_f, rng, *params):
+        B, n, dev = ro.shape[0], nc + nf, ro.device
+        t = torch.empty((B, n), device=dev)
+        w = torch.empty((B, n), device=dev)
+        depth = torch.empty((B,), device=dev)
+        rgb_map = torch.empty((B, 3), device=dev)
+        pc, pl = hc.ready(prec), hl.ready(prec)
+        ws_bytes = lib.nerfx_render_train_workspace_bytes(pl, prec, B, nc, nf)
+        if ws_bytes < 0:
+            raise _lib.NerfxError("nerfx_render_train_workspace_bytes rejected its arguments")
+        ws = torch.empty((max(ws_bytes, 1),), device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            check(lib.nerfx_render_train_fwd(pc, pl if nf > 0 else None, prec, _p(ro), _p(rd), B, tn, tf, nc, nf, _p(u_c),
+                                             _p(u_f), None if rng is None else C.byref(rng), _p(ws), ws_bytes,
+                                             _p(t), _p(w), _p(depth), _p(rgb_map), _stream()))
+        ctx.handle, ctx.prec, ctx.ws, ctx.ws_bytes, ctx.shape = hl, prec, ws, ws_bytes, (B, nc, nf)
+        ctx.param_meta = [(tuple(p.shape), p.requires_grad) for p in params]
+        ctx.save_for_backward(rd, t)
+        ctx.mark_non_differentiable(t)
+        return t, w, depth, rgb_map
+
+    @staticmethod
+    def backward(ctx, g_t, g_w, g_depth, g_rgb_map):
+        rd, t = ctx.saved_tensors
+        B, nc, nf = ctx.shape
+        dev = rd.device
+        g_w = None if g_w is None else _dev(g_w, "g_weights")
+        g_depth = None if g_depth is None else _dev(g_depth, "g_depth")
+        g_rgb_map = None if g_rgb_map is None else _dev(g_rgb_map, "g_rgb_map")
+        # one flat buffer, one view per parameter in module.parameters() order (distributed.flat_gradient)
+        sizes = [int(torch.Size(shape).numel()) if need else 0 for shape, need in ctx.param_meta]
+        flat = torch.empty((sum(sizes),), device=dev)
+        grads = [v.view(shape) if need else None for v, (shape, need) in zip(flat.split(sizes), ctx.param_meta)]
+        slots = [None, None] + grads                                 # the two encoder tables come first
+        arr = (C.c_void_p * len(slots))(*[None if g is None else g.data_ptr() for g in slots])
+        if B > 0:
+            with torch.cuda.device(dev):
+                check(lib.nerfx_render_bwd(ctx.handle.ptr, ctx.prec, _p(rd), B, nc, nf, _p(t), _p(g_rgb_map), _p(g_depth),
+                                           _p(g_w), _p(ctx.ws), ctx.ws_bytes, arr, len(slots), _stream()))
+        else:
+            grads = [None if g is None else g.zero_() for g in grads]
+        ctx.ws = None
+        return (None,) * 12 + tuple(grads)
+
+
 def _field_with_grad(module, p0, p1, t):
     handle = handle_for(module)
     params = [p for p in handle._sources[2:]]
@@ -455,28 +532,21 @@ def field_forward(module, rx: Tensor, rd: Tensor):
     return sigma, rgb.reshape(*rx.shape[:-1], 3)
 
 
-def render_train(coarse, fine, ro, rd, tn, tf, nc, nf, u_c, u_f):
+def render_train(coarse, fine, ro, rd, tn, tf, nc, nf, u_c, u_f, rng=None):
     """render_volume(train=True): the coarse pass and the sample positions are graph-free
-    (reference renderer.py:133-135); gradients reach `fine` through its MLP and the compositor."""
+    (reference renderer.py:133-135); gradients reach `fine` (the module of the last pass: `coarse`
+    itself when nf == 0) through its MLP and the compositor.  Jitter as in `render`."""
     ro, rd = _dev(ro, "ro"), _dev(rd, "rd")
     u_c = None if u_c is None else _dev(u_c, "u_c")
     u_f = None if u_f is None else _dev(u_f, "u_f")
-    with torch.no_grad():
-        t = sample_encode(ro, rd, tn, tf, nc, u_c, want_rx=False)["t"]
-        if nf > 0:
-            sigma_c, _ = mlp_rays(handle_for(coarse), ro, rd, t, density_only=True)
-            w_c, _, _ = composite_fwd(sigma_c, None, t, rd, want_depth=False)
-            t = pdf_sample(t, w_c, nf, u_f)
     if nf > 0:
         fine.requires_grad(True)                                    # reference renderer.py:137
+    hc, hl = handle_for(coarse), handle_for(fine)
     if _wants_grad(fine):
-        sigma, rgb = _field_with_grad(fine, ro, rd, t)
-        w, rgb_map, depth = _CompositeFunction.apply(sigma, rgb, t, rd)
-    else:
-        with torch.no_grad():
-            sigma, rgb = mlp_rays(handle_for(fine), ro, rd, t)
-            w, rgb_map, depth = composite_fwd(sigma, rgb, t, rd)
-    return t, w, depth, rgb_map
+        params = list(hl._sources[2:])
+        return _RenderTrainFunction.apply(hc, hl, precision(), ro, rd, tn, tf, nc, nf, u_c, u_f, rng, *params)
+    with torch.no_grad():
+        return render(hc, hl if nf > 0 else None, ro, rd, tn, tf, nc, nf, u_c, u_f, rng=rng)
 
 
 # ---- camera rays in, display frames out ---------------------------------------------
@@ -601,6 +671,19 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
     with torch.cuda.device(param.device):
         check(lib.nerfx_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lr, beta1, beta2, eps,
                                   weight_decay, _p(inv_scale), _p(found_inf), _p(step_in), _p(step_out), _stream()))
+
+
+def voxel_sample(domain, voxels: int, samples: int, device, rng=None):
+    """One distillation batch drawn by the sampling kernel: rx, rd (voxels * samples, 3), delta (voxels * samples)."""
+    dev = _device(device)
+    rng = next_rng(dev) if rng is None else rng
+    n = voxels * samples
+    rx, rd, delta = torch.empty((n, 3), device=dev), torch.empty((n, 3), device=dev), torch.empty((n,), device=dev)
+    with torch.cuda.device(dev):
+        check(lib.nerfx_voxel_sample(domain.x[0], domain.x[1], domain.y[0], domain.y[1], domain.z[0], domain.z[1],
+                                     domain.d[0], domain.d[1], voxels, samples, rng.seed, rng.offset,
+                                     _p(rx), _p(rd), _p(delta), _stream()))
+    return rx, rd, delta
 
 
 class _DistillLossFunction(torch.autograd.Function):

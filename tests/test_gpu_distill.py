@@ -87,3 +87,36 @@ def test_voxel_sampler_on_device(ops):
     # samples stay near their voxel: 8 consecutive rows share one grid point up to the jitter
     spread = (rx.view(4, 8, 3) - rx.view(4, 8, 3).mean(dim=1, keepdim=True)).abs().max()
     assert float(spread) < 6 * 0.5 * float(vs.voxel_size.max())
+
+
+def test_voxel_sampler_follows_its_uniforms(ops):
+    """The sampling kernel against a restatement of distill.py:62-82 on the very uniforms it draws
+    (cell choice, Box-Muller jitter of half a cell, normalised directions, lengths), and its
+    reproducibility under torch.manual_seed."""
+    import math
+    import nerf_amd.distill as D
+    dom = D.Domain(x=(-2.0, 3.0), y=(0.5, 4.5), z=(-1.0, 1.0), d=(0.01, 0.05))
+    V, S = 5, 7
+    vs = D.VoxelSampler(dom, voxels=V, samples=S)
+    torch.manual_seed(5)
+    rx, rd, delta = vs.sample()
+    torch.manual_seed(5)
+    rng = ops.next_rng(rx.device)
+    n = V * S
+    u_cell = ops.rng_uniform(rng, 0, V, "cuda").cpu()
+    u_jit = ops.rng_uniform(rng, 1, 6 * n, "cuda").cpu().view(n, 3, 2)
+    u_dir = ops.rng_uniform(rng, 2, 3 * n, "cuda").cpu().view(n, 3)
+    u_len = ops.rng_uniform(rng, 3, n, "cuda").cpu()
+    cell = (u_cell * float(V ** 3)).to(torch.int64).clamp_max(V ** 3 - 1)
+    centres = vs.rx.cpu()[cell.repeat_interleave(S)]                       # (n, 3): distill.py:73
+    normal = torch.sqrt(-2.0 * torch.log(1.0 - u_jit[..., 0])) * torch.cos(2.0 * math.pi * u_jit[..., 1])
+    want_rx = centres + normal * (0.5 * vs.voxel_size.cpu()[None, :])       # distill.py:74
+    want_rd = u_dir / u_dir.norm(dim=-1, keepdim=True)                      # distill.py:76-77
+    want_delta = dom.d[0] + abs(dom.d[1] - dom.d[0]) * u_len               # distill.py:79-80
+    assert_close(rx.cpu(), want_rx, rtol=1e-5, atol=1e-5, what="rx")
+    assert_close(rd.cpu(), want_rd, rtol=1e-6, atol=1e-7, what="rd")
+    assert_close(delta.cpu(), want_delta, rtol=1e-6, atol=0, what="delta")
+    torch.manual_seed(5)
+    again = vs.sample()
+    assert all(torch.equal(a, b) for a, b in zip((rx, rd, delta), again))
+    assert not torch.equal(vs.sample()[0], rx)                              # the next call draws afresh

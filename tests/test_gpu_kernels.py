@@ -303,29 +303,90 @@ def test_render_volume_golden(ops, name):
     assert_close(depth16.cpu(), g["det_depth"], rtol=2e-2, atol=2e-2, what="bf16 depth")
 
 
-def test_render_perturb_uses_torch_generator(ops):
-    """perturb=True draws rand(B,Nc) then rand(B,Nf) from the device generator, coarse first."""
+def test_render_perturb_draws_in_kernel(ops):
+    """perturb=True draws its uniforms inside the sampling kernels from a Philox stream keyed by
+    torch's device generator (seed, offset): the render equals one fed the same uniforms as arrays
+    (and so the oracle's on them), torch.manual_seed reproduces it, consecutive calls differ, and
+    the odd-sized sampling kernels draw the same numbers as the vectorised ones."""
     from nerf_amd.core import BoundedVolumeRaymarcher
     meta, g = load_golden("g6_render_student_student_64_128")
     model = product_model(meta["coarse"], g, "c_")
     bvr = BoundedVolumeRaymarcher(2.0, 6.0, 64, 128)
     ro, rd = dev(g["ro"]), dev(g["rd"])
+    B = ro.shape[0]
     ops.set_precision("fp32")
     torch.manual_seed(99)
     got = bvr.render_volume(model, model, ro, rd, perturb=True)
+    other = bvr.render_volume(model, model, ro, rd, perturb=True)           # next call: fresh jitter
     torch.manual_seed(99)
-    u_c = torch.rand(24, 64, device="cuda")
-    u_f = torch.rand(24, 128, device="cuda")
+    rng = ops.next_rng(ro.device)                                            # what that first call used
+    u_c = ops.rng_uniform(rng, 0, B * 64, ro.device).view(B, 64)
+    u_f = ops.rng_uniform(rng, 1, B * 128, ro.device).view(B, 128)
     h = ops.handle_for(model)
     want = ops.render(h, h, ro, rd, 2.0, 6.0, 64, 128, u_c, u_f, prec=0)
-    ops.set_precision(None)
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+    assert not torch.equal(got[0], other[0])
+    torch.manual_seed(99)
+    again = bvr.render_volume(model, model, ro, rd, perturb=True)
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
     om = oracle_model(meta["coarse"], g, "c_")
     with torch.no_grad():
         ref = O.render_volume(om, om, g["ro"], g["rd"], 2.0, 6.0, 64, 128, u_c.cpu(), u_f.cpu())
     assert_close(got[3].cpu(), ref[3], rtol=1e-5, atol=1e-5, what="rgb")
     assert_close(got[2].cpu(), ref[2], rtol=1e-5, atol=1e-5, what="depth")
+    # sample counts that are not multiples of four take the per-element kernels: same stream
+    u7 = ops.rng_uniform(rng, 0, B * 7, ro.device).view(B, 7)
+    u9 = ops.rng_uniform(rng, 1, B * 9, ro.device).view(B, 9)
+    a = ops.render(h, h, ro, rd, 2.0, 6.0, 7, 9, prec=0, rng=rng)
+    b = ops.render(h, h, ro, rd, 2.0, 6.0, 7, 9, u7, u9, prec=0)
+    ops.set_precision(None)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon et al., SC'11) on numpy uint32 arrays: counter (n, 4), key (2,)."""
+    import numpy as np
+    c = counter.astype(np.uint64).copy()
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[:, 0]
+        p1 = np.uint64(0xCD9E8D57) * c[:, 2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[:, 1] ^ k0) & m32
+        n2 = ((p0 >> np.uint64(32)) ^ c[:, 3] ^ k1) & m32
+        c = np.stack([n0, p1 & m32, n2, p0 & m32], axis=1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return c.astype(np.uint32)
+
+
+def test_rng_is_philox4x32_10(ops):
+    """The in-kernel generator against an independent Philox4x32-10, itself pinned by the
+    known-answer vectors its authors publish (Random123 kat_vectors), plus first and second
+    moments of a large draw."""
+    import numpy as np
+    from nerf_amd import _lib
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = philox4x32_10(np.array([ctr], dtype=np.uint32), np.array(key, dtype=np.uint32))[0]
+        assert tuple(int(x) for x in got) == want
+    seed, offset, n = 0x0123456789ABCDEF, 0x1000000044, 4099
+    for which in (0, 1):
+        got = ops.rng_uniform(_lib.Rng(seed, offset), which, n, "cuda").cpu().numpy()
+        blocks = np.arange((n + 3) // 4, dtype=np.uint64)
+        hi = (offset ^ (which * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+        ctr = np.stack([blocks & 0xFFFFFFFF, blocks >> np.uint64(32), np.full_like(blocks, hi & 0xFFFFFFFF),
+                        np.full_like(blocks, hi >> 32)], axis=1).astype(np.uint32)
+        words = philox4x32_10(ctr, np.array([seed & 0xFFFFFFFF, seed >> 32], dtype=np.uint32)).reshape(-1)[:n]
+        want = (words >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+        assert np.array_equal(got, want), which
+    big = ops.rng_uniform(_lib.Rng(7, 0), 0, 1 << 22, "cuda")
+    assert float(big.min()) >= 0.0 and float(big.max()) < 1.0
+    assert abs(float(big.mean()) - 0.5) < 1e-3 and abs(float(big.var()) - 1.0 / 12.0) < 1e-3
 
 
 def test_infer_golden(ops):
