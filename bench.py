@@ -113,7 +113,7 @@ def run_roofline(step, prec, steps):
             mlp_flop += b * n * (FLOP_FULL if colour else FLOP_DENSITY)
             mlp_launches += 1
     achieved = mlp_flop / (stage_ms["mlp"] * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "mlp_fwd_kernel", "achieved": achieved, "peak": PEAK_TFLOPS[prec],
+    roof = {"bound": "mfma", "kernel": "mlp_fwd16_kernel" if prec == "bf16" else "mlp_fwd_kernel", "achieved": achieved, "peak": PEAK_TFLOPS[prec],
             "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[prec], "traffic": None, "launches": mlp_launches,
             "avg_launch_ms": stage_ms["mlp"] / mlp_launches, "flop_per_launch": mlp_flop / mlp_launches,
             "measured": f"HIP events around every kernel of {steps} staged steps after the timed region"}

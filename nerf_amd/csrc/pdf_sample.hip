@@ -56,7 +56,10 @@ __device__ __forceinline__ void wave_sync() {
 
 // R = values of each row a lane holds: the kernel is instantiated for rows of up to 64, 128 and
 // 256 samples, so the usual 64 + 64 case carries no loops or predicates for longer rows.
-template <int R>
+// MODE = where the inverse-CDF positions come from: 0 linspace(0, 1, nf), 1 the caller's uniforms,
+// 2 drawn in the kernel; a template parameter so that the unperturbed kernel carries neither the
+// uniform rows nor the generator.
+template <int R, int MODE>
 __global__ __launch_bounds__(64) void pdf_sample_kernel(
     const float* __restrict__ t_c, const float* __restrict__ w_c, int64_t n_rays, int nc, int nf,
     const float* __restrict__ u_g, Rng rng, float* __restrict__ t_sorted, float* __restrict__ cdf_out,
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
             const int i = lane + 64 * q;
             tr[q] = i < nc ? t_c[ray * nc + i] : 0.f;
             wr[q] = i < nc ? w_c[ray * nc + i] : 0.f;
-            ur[q] = (u_g && i < nf) ? u_g[ray * nf + i] : 0.f;
+            ur[q] = (MODE == 1 && i < nf) ? u_g[ray * nf + i] : 0.f;
         }
     };
     // The hand-over cur <- nxt sits in the MIDDLE of an iteration, before the output stores: the
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
         for (int q = 0; q < R; ++q) {
             const int j = lane + 64 * q;
             if (j >= nf) continue;
-            const float u = u_g ? u_cur[q] : (rng.on ? rng_uniform(rng, (uint64_t)(ray * nf + j)) : linspace_at(0.f, 1.f, nf, j));
+            const float u = MODE == 1 ? u_cur[q] : (MODE == 2 ? rng_uniform(rng, (uint64_t)(ray * nf + j)) : linspace_at(0.f, 1.f, nf, j));
             const int idx = upper_bound(cdf, nb, u);
             const int below = max(idx - 1, 0), above = min(idx, nw);
             const float cb = cdf[below], ca = cdf[above], bb = bins[below], ba = bins[above];
@@ -245,7 +248,11 @@ int pdf_sample_launch(const float* t_c, const float* w_c, int64_t n_rays, int nc
     NERFX_REQUIRE(t_c && w_c && t_sorted, "t_c / w_c / t_sorted is NULL");
     const int grid = (int)std::min<int64_t>(n_rays, 256 * 32);
     const int longest = std::max(nc, nf);
-    auto kern = longest <= 64 ? pdf_sample_kernel<1> : (longest <= 128 ? pdf_sample_kernel<2> : pdf_sample_kernel<4>);
+    using Kernel = void (*)(const float*, const float*, int64_t, int, int, const float*, Rng, float*, float*, int64_t*, float*);
+    static const Kernel table[3][3] = {{pdf_sample_kernel<1, 0>, pdf_sample_kernel<1, 1>, pdf_sample_kernel<1, 2>},
+                                       {pdf_sample_kernel<2, 0>, pdf_sample_kernel<2, 1>, pdf_sample_kernel<2, 2>},
+                                       {pdf_sample_kernel<4, 0>, pdf_sample_kernel<4, 1>, pdf_sample_kernel<4, 2>}};
+    const Kernel kern = table[longest <= 64 ? 0 : (longest <= 128 ? 1 : 2)][u ? 1 : (rng.on ? 2 : 0)];
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, stream, t_c, w_c, n_rays, nc, nf, u, rng, t_sorted, cdf, idx, t_pdf);
     return launch_status("pdf_sample_kernel");
 }

@@ -110,6 +110,8 @@ __global__ __launch_bounds__(256) void sample_t_kernel(const float* __restrict__
 // consecutive samples of one ray and keeps its sample slot while it walks over rays, so the
 // index arithmetic is one 32-bit division per thread and every store is 128 bits wide.
 // With the generator, a thread's four samples are exactly one Philox block.
+// MODE = where the jitter comes from: 0 none, 1 the caller's uniforms, 2 drawn in the kernel.
+template <int MODE>
 __global__ __launch_bounds__(256) void sample_t4_kernel(const float* __restrict__ rd, int64_t n_rays, float tn, float tf,
                                                         int n, const float* __restrict__ u, Rng rng, float* __restrict__ t_out,
                                                         float* __restrict__ delta_out) {
@@ -122,21 +124,25 @@ __global__ __launch_bounds__(256) void sample_t4_kernel(const float* __restrict_
     for (int64_t ray = (int64_t)blockIdx.x * rpb + slot; ray < n_rays; ray += (int64_t)gridDim.x * rpb) {
         const int64_t q = ray * n + i0;
         float t[5];
-        if (u) {
-            const float4 uv = *reinterpret_cast<const float4*>(u + q);
-            t[0] = stratified_at(tn, tf, n, i0, uv.x);
-            t[1] = stratified_at(tn, tf, n, i0 + 1, uv.y);
-            t[2] = stratified_at(tn, tf, n, i0 + 2, uv.z);
-            t[3] = stratified_at(tn, tf, n, i0 + 3, uv.w);
-            t[4] = i0 + 4 < n ? stratified_at(tn, tf, n, i0 + 4, u[q + 4]) : 0.0f;
-        } else if (rng.on) {
-            const Philox4 b = rng_block(rng, (uint64_t)q >> 2);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = stratified_at(tn, tf, n, i0 + e, rng_to_float(b.w[e]));
-            t[4] = (delta_out && i0 + 4 < n) ? stratified_at(tn, tf, n, i0 + 4, rng_uniform(rng, (uint64_t)q + 4)) : 0.0f;
-        } else {
+        if (MODE == 0) {
 #pragma unroll
             for (int e = 0; e < 5; ++e) t[e] = lin[e];
+        } else {
+            float uv[4];
+            if (MODE == 1) {
+                const float4 v = *reinterpret_cast<const float4*>(u + q);
+                uv[0] = v.x; uv[1] = v.y; uv[2] = v.z; uv[3] = v.w;
+            } else {
+                const Philox4 b = rng_block(rng, (uint64_t)q >> 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) uv[e] = rng_to_float(b.w[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = stratified_at(tn, tf, n, i0 + e, uv[e]);
+            // The first sample of the next four belongs to the next lane, except across a wavefront's edge.
+            t[4] = __shfl_down(t[0], 1, 64);
+            if (delta_out && i0 + 4 < n && (threadIdx.x & 63) == 63)
+                t[4] = stratified_at(tn, tf, n, i0 + 4, MODE == 1 ? u[q + 4] : rng_uniform(rng, (uint64_t)q + 4));
         }
         if (t_out) *reinterpret_cast<float4*>(t_out + q) = make_float4(t[0], t[1], t[2], t[3]);
         if (delta_out) {                                               // ray.py:62-65
@@ -189,7 +195,8 @@ int sample_t_launch(const float* rd, int64_t n_rays, float tn, float tf, int n_s
     if (n_samples % 4 == 0 && aligned) {
         const int rpb = 256 / (n_samples / 4);
         const int grid4 = (int)std::min<int64_t>((n_rays + rpb - 1) / rpb, 256 * 16);
-        hipLaunchKernelGGL(sample_t4_kernel, dim3(grid4), dim3(256), 0, stream, rd, n_rays, tn, tf, n_samples, u, rng, t, delta);
+        auto kern = u ? sample_t4_kernel<1> : (rng.on ? sample_t4_kernel<2> : sample_t4_kernel<0>);
+        hipLaunchKernelGGL(kern, dim3(grid4), dim3(256), 0, stream, rd, n_rays, tn, tf, n_samples, u, rng, t, delta);
         return launch_status("sample_t4_kernel");
     }
     const int grid = (int)std::min<int64_t>((n_rays * n_samples + 255) / 256, 256 * 16);
