@@ -27,7 +27,7 @@ struct BwdArgs {
     const float* rgb;            // (M,3) are formed from them
     uint32_t n_points, n_blocks, n_pieces;
     int hd, sigw_off, const_floats;
-    int z_tile[MAX_LAYERS], heads_tile;
+    int z_tile[MAX_LAYERS], heads_tile, n_tiles;
 };
 
 template <int PREC, int ACT>
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
             }
             gs = a.g_sigma[m] * -expm1f(-a.sigma[m]);
         }
-        const Tape<PREC> zt{(typename Tape<PREC>::T*)a.ztape, a.m_pad, m, (uint16_t*)a.stape};
-        const Tape<PREC> gt{(typename Tape<PREC>::T*)a.gtape, a.m_pad, m};
+        const Tape<PREC> zt{(typename Tape<PREC>::T*)a.ztape, a.m_pad, m, (uint16_t*)a.stape, (uint32_t)a.n_tiles};
+        const Tape<PREC> gt{(typename Tape<PREC>::T*)a.gtape, a.m_pad, m, nullptr, (uint32_t)a.n_tiles};
         if (h == 0) {                                               // heads tile: positions 0..2 and 3
             using TT = typename Tape<PREC>::T;
             TT* p = gt.at(a.heads_tile, 0);

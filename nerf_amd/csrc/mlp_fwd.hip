@@ -75,7 +75,7 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
         a.tape_signs = tape_signs;
         a.tape_m_pad = tape_m_pad(n_points);
         a.n_blocks = (uint32_t)(a.tape_m_pad / (32 * waves));       // pad columns are written too
-        a.tape_ex_tile = p.tape_ex_tile; a.tape_ed_tile = p.tape_ed_tile;
+        a.tape_ex_tile = p.tape_ex_tile; a.tape_ed_tile = p.tape_ed_tile; a.tape_tiles = p.tape_tiles;
         for (int li = 0; li < p.n_layers; ++li) a.tape_z_tile[li] = p.tape_z_tile[li];
         const bool small_enc = a.ex_units <= ENC_BLOCK && a.ed_units <= ENC_BLOCK;
         if (small_enc && p.wt == 8 && p.desc.resid && (p.hd == 2 || p.hd == 4))
@@ -193,7 +193,7 @@ extern "C" int nerfx_mlp_bwd(const nerfx_model_t* model, int precision, int64_t 
     a.n_pieces = (uint32_t)(p.bwd_units / PIECE_UNITS);
     a.hd = p.hd; a.sigw_off = p.sigw_off; a.const_floats = p.const_floats;
     for (int li = 0; li < p.n_layers; ++li) a.z_tile[li] = p.tape_z_tile[li];
-    a.heads_tile = p.tape_heads_tile;
+    a.heads_tile = p.tape_heads_tile; a.n_tiles = p.tape_tiles;
     if (int rc = (precision == NERFX_PREC_BF16 ? launch_mlp_bwd_bf16 : launch_mlp_bwd_fp32)(p.desc.activ, p.wt, a, (hipStream_t)stream))
         return rc;
     return launch_wgrad(model, precision, w.m_pad, w.ztape, w.gtape, w.partial, grads, n_grads, (hipStream_t)stream);

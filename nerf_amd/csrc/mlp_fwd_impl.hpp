@@ -57,6 +57,7 @@ struct MlpArgs {
     void* tape_signs;            // bf16 training forward: the sign words of the tape (see Tape::signs)
     uint64_t tape_m_pad;         // samples per tape tile
     int tape_ex_tile, tape_ed_tile, tape_z_tile[MAX_LAYERS];   // first tile of each encoder / layer
+    int tape_tiles;              // tiles in the tape (checked builds trap on anything beyond)
 };
 
 // ---- optional in-kernel cycle accounting (diagnostic builds only: -DNERFX_STAMPS) -------
@@ -102,7 +103,22 @@ struct Tape {
     // and lane half holding the signs of its 16 values (bit 15 - r = sign bit of register r).  The
     // backward chain needs nothing else of z, so it reads 2 bytes where the tile has 32.
     uint16_t* signs = nullptr;
-    __device__ __forceinline__ uint16_t* sign_at(int tile, int h) const { return signs + ((uint64_t)tile * m_pad + m) * 2 + h; }
+    uint32_t n_tiles = 0;        // tiles the tape holds (0: not known, nothing is checked)
+    // Every tape address goes through here.  A checked build (`make checked`, -DNERFX_CHECK_TAPE) traps
+    // on a tile or sample outside the tape instead of letting the access fault the GPU or land in a
+    // neighbouring allocation; the product build compiles this to nothing.
+    __device__ __forceinline__ void check(int tile, int pos) const {
+#ifdef NERFX_CHECK_TAPE
+        if (n_tiles && ((uint32_t)tile >= n_tiles || (uint64_t)m >= m_pad || (uint32_t)pos >= 32u)) {
+            printf("nerfx: tape access outside the tape: tile %d of %u, sample %u of %llu, position %d (block %u, thread %u)\n",
+                   tile, n_tiles, m, (unsigned long long)m_pad, pos, blockIdx.x, threadIdx.x);
+            __builtin_trap();
+        }
+#else
+        (void)tile; (void)pos;
+#endif
+    }
+    __device__ __forceinline__ uint16_t* sign_at(int tile, int h) const { check(tile, h); return signs + ((uint64_t)tile * m_pad + m) * 2 + h; }
     static __device__ __forceinline__ uint32_t sign_word(const f32x16& v) {
         uint32_t bits = 0;
 #pragma unroll
@@ -112,7 +128,7 @@ struct Tape {
         }
         return bits & 0xFFFFu;
     }
-    __device__ __forceinline__ T* at(int tile, int pos) const { return base + ((uint64_t)tile * m_pad + m) * 32 + pos; }
+    __device__ __forceinline__ T* at(int tile, int pos) const { check(tile, pos); return base + ((uint64_t)tile * m_pad + m) * 32 + pos; }
     // (callers make sure `v` does not come straight out of an MFMA: the bf16 form converts in asm)
     __device__ __forceinline__ void store_tile(int tile, int h, const f32x16& v) const {
         T* p = at(tile, 16 * h);
@@ -683,7 +699,7 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         // in registers, (re)built right before each consuming layer.
         Encoding<PREC> enc;
         enc.template prepare<BIGENC>(a.ex_kind, a.ex_units, cst + a.tabx_off, h, px, py, pz);
-        Tape<PREC> tape{(typename Tape<PREC>::T*)a.tape, a.tape_m_pad, m, (uint16_t*)a.tape_signs};   // m < m_pad also for tail lanes
+        Tape<PREC> tape{(typename Tape<PREC>::T*)a.tape, a.tape_m_pad, m, (uint16_t*)a.tape_signs, (uint32_t)a.tape_tiles};   // m < m_pad also for tail lanes
         const Tape<PREC>* zt = TRAIN ? &tape : nullptr;
         if constexpr (TRAIN && !BIGENC) {                           // wide encoders are recorded where they are evaluated
 #pragma unroll
