@@ -48,7 +48,16 @@ constexpr int MAX_TABLE = 1024;                 // floats per encoder table
 // (mlp_fwd16_impl.hpp).  Same arithmetic as NERFX_PREC_BF16; the chip sustains a higher clock on
 // this MFMA shape.  Functions below take it wherever they take a precision.
 constexpr int NERFX_LAYOUT_M16 = 2;
-constexpr int N_LAYOUTS = 3;
+// A fourth stream, for bf16 inference of the 256-wide skip models whose encoders are wider than the
+// kernels' register cache (Fourier features): NERFX_PREC_BF16 units, but a layer with an encoder
+// segment carries the encoder units of ALL its tile groups first, chunk by chunk (ENC_BLOCK k-units
+// x every group), then the chained units group by group.  The kernel evaluates a chunk of phi once
+// and multiplies it into every accumulator tile of the layer (linear_encmajor in
+// mlp_fwd_impl.hpp); in the plain order a chunk is evaluated once per tile group.
+constexpr int NERFX_STREAM_ENCMAJOR = 3;
+constexpr int N_LAYOUTS = 4;
+// precision / unit shape of a stream
+__host__ __device__ constexpr int layout_prec(int layout) { return layout == NERFX_STREAM_ENCMAJOR ? NERFX_PREC_BF16 : layout; }
 
 // slots (input features) per k-unit and k-units per 32-feature activation tile
 __host__ __device__ constexpr int slots_per_unit(int prec) { return prec == NERFX_LAYOUT_M16 ? 32 : prec == NERFX_PREC_BF16 ? 16 : 8; }
@@ -124,6 +133,7 @@ struct LayerPlan {
     int chain_dim;      // true chained inputs
     int in_dim;         // leading dimension of the reference weight (enc_cols + chain_dim)
     int group;          // NG
+    int enc_major;      // NERFX_STREAM_ENCMAJOR: all groups' encoder units first, chunk-major (see above)
     int enc_seg;        // units of one group's encoder segment (padded to pieces)
     int chain_seg;      // units of one group's chained segment (padded to pieces)
     int64_t unit0;      // first unit of this layer in the stream
@@ -159,8 +169,14 @@ struct ModelPlan {
 
 __host__ __device__ inline int units_of(const LayerPlan& L) { return (L.n_tiles / L.group) * (L.enc_seg + L.chain_seg); }
 
-// Fills `p` from a model description; returns 0 or an error code.
-int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p);
+// Fills `p` from a model description for stream layout `layout`; returns 0 or an error code.
+int make_plan(const nerfx_model_desc_t& d, int layout, ModelPlan& p);
+// Models the encoder-major stream is packed for: 256-wide (8 tiles), skip connection, depth 4 or 8,
+// an encoder wider than ENC_BLOCK bf16 k-units.
+inline bool encmajor_supported(const nerfx_model_desc_t& d) {
+    return d.width > 128 && d.width <= 256 && d.resid && (d.depth == 4 || d.depth == 8) &&
+           (enc_units(d.enc_x_kind, d.enc_x_n, NERFX_PREC_BF16) > ENC_BLOCK || enc_units(d.enc_d_kind, d.enc_d_n, NERFX_PREC_BF16) > ENC_BLOCK);
+}
 // Models the M16 inference kernel takes: 129..256 wide, skip connection, depth 4 or 8, encoders
 // of at most 64 slots (positional up to 10 frequencies, Fourier up to 32 features).
 inline bool m16_supported(const nerfx_model_desc_t& d) {
@@ -180,6 +196,8 @@ struct nerfx_model {
     nerfx::ModelPlan plan[nerfx::N_LAYOUTS];          // indexed by NERFX_PREC_* / NERFX_LAYOUT_M16
     void* stream_dev[nerfx::N_LAYOUTS];               // packed unit streams
     bool has_m16;                      // the M16 stream exists (see m16_supported)
+    bool has_encmajor;                 // the encoder-major stream exists (see encmajor_supported)
+    bool has_layout(int l) const { return l == nerfx::NERFX_LAYOUT_M16 ? has_m16 : l == nerfx::NERFX_STREAM_ENCMAJOR ? has_encmajor : true; }
     void* stream_bwd_dev[2];           // packed backward (transposed) unit streams
     nerfx::LayerPlan* plans_dev[nerfx::N_LAYOUTS];    // forward then backward layer plans (read by the pack kernel)
     void* wtasks_dev[2];               // weight-gradient task tables (mlp_wgrad.hip)

@@ -90,8 +90,12 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
     }
     // encoders that fit the kernels' register cache take the fast instantiations
     const bool big = a.ex_units > ENC_BLOCK || a.ed_units > ENC_BLOCK;
-    if (big && precision == NERFX_PREC_BF16 && p.wt == 8 && p.desc.resid && (p.hd == 2 || p.hd == 4))
+    if (precision == NERFX_PREC_BF16 && model->has_encmajor) {                 // wide encoders: the encoder-major stream
+        const ModelPlan& pe = model->plan[NERFX_STREAM_ENCMAJOR];
+        a.stream = (const char*)model->stream_dev[NERFX_STREAM_ENCMAJOR];
+        a.n_pieces = (uint32_t)((rgb ? pe.total_units : pe.trunk_units) / PIECE_UNITS);
         return launch_mlp_bf16_bigenc_fixed(p.desc.activ, p.hd, a, (hipStream_t)stream);
+    }
     if (!big && p.wt == 8 && p.desc.resid && (p.hd == 2 || p.hd == 4))          // compile-time depth
         return (precision == NERFX_PREC_BF16 ? launch_mlp_bf16_fixed : launch_mlp_fp32_fixed)(p.desc.activ, p.hd, a, (hipStream_t)stream);
     auto launch = precision == NERFX_PREC_BF16 ? (big ? launch_mlp_bf16_bigenc : launch_mlp_bf16)

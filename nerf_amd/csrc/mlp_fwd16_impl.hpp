@@ -124,7 +124,8 @@ struct Act16 { Frag16 f[M16_KU][2]; };          // one layer's activations: [k-u
 
 // B operand of encoder k-unit u for lane group q: slots 32 u + 8 q .. + 7 = pair-slots
 // 16 u + 4 q .. + 3 of the encoder's coefficient table (see encode_unit in mlp_fwd_impl.hpp).
-__device__ __forceinline__ Frag16 encode_unit16(lds_floats_t table, bool positional, int u, int q, float sx, float sy, float sz) {
+__device__ __forceinline__ Frag16 encode_unit16(lds_floats_t table, bool positional, int u, int q, float sx, float sy, float sz,
+                                                float x, float y, float z) {
     using P = Prec<NERFX_PREC_BF16>;
     const lds_floats_t c0 = table + 4 * (16 * u + 4 * q);
     float v[8];
@@ -134,7 +135,7 @@ __device__ __forceinline__ Frag16 encode_unit16(lds_floats_t table, bool positio
         const float angle = fmaf(sz, c[2], fmaf(sy, c[1], __fmul_rn(sx, c[0])));
         P::sincos_pair(angle, v[2 * i], v[2 * i + 1]);
     }
-    if (positional && u == 0 && q == 0) { v[0] = sx; v[1] = sy; v[2] = sz; v[3] = 0.0f; }
+    if (positional && u == 0 && q == 0) { v[0] = x; v[1] = y; v[2] = z; v[3] = 0.0f; }
     return P::from_floats(v);
 }
 
@@ -159,7 +160,6 @@ template <int ACT, int NT, int CK, bool SIGMA, int ENC>
 __device__ __forceinline__ void linear16(PhasedRing& ring, lds_floats_t bias, int q, const Act16& hin, Act16& hout,
                                          lds_floats_t sigw, float (&dot)[2], Stamps& st, uint32_t stash,
                                          const Frag16 (&encr)[M16_ENC_KU][2]) {
-    using P = Prec<NERFX_PREC_BF16>;
     static_assert(NT % 4 == 0 && (CK == 0 || CK == M16_KU), "full groups of four tiles on 0 or 256 chained inputs");
     static_assert(CK > 0 || ENC == M16_ENC_STASH, "an encoder-only layer reads the stash");
     constexpr int ENC_UNITS = ENC != M16_ENC_NONE ? 8 : 0, UNITS = ENC_UNITS + 4 * CK;
@@ -261,7 +261,8 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
     const bool colour = a.rgb != nullptr;
     constexpr int LAST = 2 * HD - 1;                                // last trunk layer feeds the density head
     const bool x_positional = a.ex_kind == NERFX_ENC_POSITIONAL, d_positional = a.ed_kind == NERFX_ENC_POSITIONAL;
-    const float x_scale = x_positional ? 1.0f : 6.283185307179586f, d_scale = d_positional ? 1.0f : 6.283185307179586f;
+    // coordinates as the pair tables want them, in revolutions: v / 2 pi (positional), 2 pi v / 2 pi (Fourier)
+    const float x_scale = x_positional ? P::ANGLE_UNIT : 1.0f, d_scale = d_positional ? P::ANGLE_UNIT : 1.0f;
 
     Stamps st;
     st.start();
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
 #pragma unroll
             for (int u = 0; u < M16_ENC_KU; ++u)
                 *reinterpret_cast<__attribute__((address_space(3))) Frag16*>(my_stash + (2 * u + s) * UNIT_BYTES) =
-                    encode_unit16(cst + a.tabx_off, x_positional, u, q, sx, sy, sz);
+                    encode_unit16(cst + a.tabx_off, x_positional, u, q, sx, sy, sz, px[s], py[s], pz[s]);
         }
         // same wave reads it back: LDS is in order per wave
         const uint32_t stash = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(stash_base + wave * M16_STASH_BYTES_PER_WAVE));
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
             for (int s = 0; s < 2; ++s) {
                 const float sx = __fmul_rn(d_scale, dx[s]), sy = __fmul_rn(d_scale, dy[s]), sz = __fmul_rn(d_scale, dz[s]);
 #pragma unroll
-                for (int u = 0; u < M16_ENC_KU; ++u) encr[u][s] = encode_unit16(cst + a.tabd_off, d_positional, u, q, sx, sy, sz);
+                for (int u = 0; u < M16_ENC_KU; ++u) encr[u][s] = encode_unit16(cst + a.tabd_off, d_positional, u, q, sx, sy, sz, dx[s], dy[s], dz[s]);
             }
             st.mark(ST_ENCODE);
             linear16<ACT, 8, M16_KU, false, M16_ENC_REGS>(ring, cst + li * BIAS_STRIDE, q, A, B, sigw, dot, st, stash, encr);

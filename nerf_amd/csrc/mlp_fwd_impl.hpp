@@ -317,9 +317,11 @@ template <> struct Prec<NERFX_PREC_BF16> {
     static __device__ __forceinline__ void mma(f32x16& acc, const AFrag& a, const Frag& b) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
-    static __device__ __forceinline__ void sincos_pair(float angle, float& s, float& c) {
-        float r = angle * 0.15915494309189535f;             // revolutions
-        r = r - floorf(r);
+    // The hardware sine / cosine take revolutions: the coordinates are scaled once per sample
+    // (ANGLE_UNIT) so that the pair table's dot product comes out in revolutions.
+    static constexpr float ANGLE_UNIT = 0.15915494309189535f;
+    static __device__ __forceinline__ void sincos_pair(float revolutions, float& s, float& c) {
+        const float r = __builtin_amdgcn_fractf(revolutions);
         s = __builtin_amdgcn_sinf(r);
         c = __builtin_amdgcn_cosf(r);
     }
@@ -357,6 +359,7 @@ template <> struct Prec<NERFX_PREC_FP32> {
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
     }
+    static constexpr float ANGLE_UNIT = 1.0f;              // radians
     static __device__ __forceinline__ void sincos_pair(float angle, float& s, float& c) { sincosf(angle, &s, &c); }
     static __device__ __forceinline__ float expneg(float x) { return expf(-x); }
     static __device__ __forceinline__ float sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -368,11 +371,12 @@ template <> struct Prec<NERFX_PREC_FP32> {
 
 // B operand of encoder k-unit u for this lane's point: slots per enc_unit_slot() / enc_slot_col().
 // `table` is the encoder's pair-coefficient table (float4 per pair-slot, LDS); (sx, sy, sz) is
-// the point as the angles want it (v for positional, 2 pi v for Fourier: features.py:34, :51);
-// a positional encoder's unit 0 starts with the raw coordinates in lane half 0.
+// the point as the angles want it (v for positional, 2 pi v for Fourier: features.py:34, :51;
+// times the precision's ANGLE_UNIT); a positional encoder's unit 0 starts with the raw
+// coordinates (x, y, z) in lane half 0.
 template <int PREC>
 __device__ __forceinline__ typename Prec<PREC>::Frag encode_unit(lds_floats_t table, bool positional, int u, int h,
-                                                                 float sx, float sy, float sz) {
+                                                                 float sx, float sy, float sz, float x, float y, float z) {
     using P = Prec<PREC>;
     constexpr int SPUH = P::SPUH;
     const lds_floats_t c0 = table + 4 * ((SPUH * u) + (SPUH / 2) * h);       // this lane's first pair-slot
@@ -383,7 +387,7 @@ __device__ __forceinline__ typename Prec<PREC>::Frag encode_unit(lds_floats_t ta
         const float angle = fmaf(sz, c[2], fmaf(sy, c[1], __fmul_rn(sx, c[0])));
         P::sincos_pair(angle, v[2 * i], v[2 * i + 1]);
     }
-    if (positional && u == 0 && h == 0) { v[0] = sx; v[1] = sy; v[2] = sz; v[3] = 0.0f; }
+    if (positional && u == 0 && h == 0) { v[0] = x; v[1] = y; v[2] = z; v[3] = 0.0f; }
     return P::from_floats(v);
 }
 
@@ -395,21 +399,23 @@ struct Encoding {
     int units;
     bool positional;
     lds_floats_t table;
-    float sx, sy, sz;
+    float sx, sy, sz, rx, ry, rz;
     int h;
     template <bool BIGENC>
     __device__ __forceinline__ void prepare(int kind, int nu, lds_floats_t tb, int hh, float x, float y, float z) {
         positional = kind == NERFX_ENC_POSITIONAL;
-        const float scale = positional ? 1.0f : 6.283185307179586f;
+        // 2 pi x ANGLE_UNIT is exactly 1 for the revolutions of the bf16 kernels
+        const float scale = positional ? Prec<PREC>::ANGLE_UNIT : (PREC == NERFX_PREC_BF16 ? 1.0f : 6.283185307179586f);
         units = nu; table = tb; h = hh;
         sx = __fmul_rn(scale, x); sy = __fmul_rn(scale, y); sz = __fmul_rn(scale, z);
+        rx = x; ry = y; rz = z;
         if (!BIGENC) {
 #pragma unroll
-            for (int u = 0; u < ENC_BLOCK; ++u) cached[u] = encode_unit<PREC>(table, positional, u, h, sx, sy, sz);
+            for (int u = 0; u < ENC_BLOCK; ++u) cached[u] = encode_unit<PREC>(table, positional, u, h, sx, sy, sz, rx, ry, rz);
         }
     }
     __device__ __forceinline__ typename Prec<PREC>::Frag eval(int u) const {
-        return encode_unit<PREC>(table, positional, u, h, sx, sy, sz);
+        return encode_unit<PREC>(table, positional, u, h, sx, sy, sz, rx, ry, rz);
     }
 };
 
@@ -638,6 +644,98 @@ __device__ __forceinline__ float linear(WeightRing<RG>& ring, lds_floats_t bias,
     return dot;
 }
 
+// A Linear layer with an encoder segment, read from the encoder-major stream
+// (NERFX_STREAM_ENCMAJOR; bf16 inference): every chunk of ENC_BLOCK encoder k-units is evaluated
+// ONCE and multiplied into all NT accumulator tiles of the layer -- one hand-over brings the
+// chunk's weights for every tile group -- where linear<> evaluates it once per tile group.  The
+// chained input then goes group by group as in linear<>, each group followed by its epilogue, so
+// the NT accumulator tiles are live beside hin only while the encoder segment runs.
+template <class RG, int ACT, int NT, int CT, bool SIGMA, int HN_IN, int HN_OUT>
+__device__ __forceinline__ float linear_encmajor(WeightRing<RG>& ring, lds_floats_t bias, int h,
+                                                 const Prec<NERFX_PREC_BF16>::Frag (&hin)[HN_IN],
+                                                 Prec<NERFX_PREC_BF16>::Frag (&hout)[HN_OUT],
+                                                 const Encoding<NERFX_PREC_BF16>& enc, lds_floats_t sigw, Stamps& st) {
+    constexpr int PREC = NERFX_PREC_BF16;
+    using P = Prec<PREC>;
+    constexpr int NG = group_tiles(PREC, NT), GROUPS = NT / NG;
+    constexpr int SYNC_PIECES = RG::SYNC;
+    constexpr int KB_PER_PIECE = PIECE_UNITS / NG;
+    constexpr int CHAIN_KU = CT * P::UPT;
+    constexpr int CHAIN_PIECES = pad_to_piece(CHAIN_KU * NG) / PIECE_UNITS;
+    constexpr int ENC_PIECES = pad_to_piece(ENC_BLOCK * NG) / PIECE_UNITS;   // per chunk and group
+    static_assert(GROUPS * ENC_PIECES <= SYNC_PIECES, "a chunk's weights for every group arrive in one hand-over");
+    static_assert(CHAIN_PIECES % SYNC_PIECES == 0, "chained segments are whole hand-overs");
+    static_assert(CHAIN_KU <= HN_IN && NT * P::UPT <= HN_OUT, "fragment arrays too small");
+    f32x16 acc[GROUPS][NG];
+#pragma unroll
+    for (int grp = 0; grp < GROUPS; ++grp)
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            lds_floats_t bp = bias + 32 * (grp * NG + t) + 4 * h;
+            const f32x4 b0 = NERFX_LDS_VEC(f32x4, bp), b1 = NERFX_LDS_VEC(f32x4, bp + 8),
+                        b2 = NERFX_LDS_VEC(f32x4, bp + 16), b3 = NERFX_LDS_VEC(f32x4, bp + 24);
+            const f32x8 lo = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const f32x8 hi = __builtin_shufflevector(b2, b3, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[grp][t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        }
+    for (int u0 = 0; u0 < enc.units; u0 += ENC_BLOCK) {
+        st.mark(ST_EPILOGUE);
+        typename P::Frag eb[ENC_BLOCK];
+#pragma unroll
+        for (int u = 0; u < ENC_BLOCK; ++u) eb[u] = enc.eval(u0 + u);
+        st.mark(ST_ENCODE);
+        ring.template acquire<GROUPS * ENC_PIECES>();
+        st.mark(ST_ACQUIRE);
+#pragma unroll
+        for (int grp = 0; grp < GROUPS; ++grp) {
+            run_units<PREC, RG, NG, ENC_BLOCK * NG>(ring, acc[grp], [&](int u) { return eb[u]; });
+            ring.template release<ENC_PIECES>();
+        }
+        st.mark(ST_RUN);
+    }
+    float dot = 0.0f;
+#pragma unroll
+    for (int grp = 0; grp < GROUPS; ++grp) {
+        if constexpr (CHAIN_KU > 0)
+#pragma unroll
+        for (int p0 = 0; p0 < CHAIN_PIECES; p0 += SYNC_PIECES) {
+            const int ku0 = p0 * KB_PER_PIECE;
+            constexpr int KU = SYNC_PIECES * KB_PER_PIECE;
+            st.mark(ST_EPILOGUE);
+            ring.template acquire<SYNC_PIECES>();
+            st.mark(ST_ACQUIRE);
+            run_units<PREC, RG, NG, KU * NG>(ring, acc[grp], [&](int k) { return hin[ku0 + k]; });
+            st.mark(ST_RUN);
+            ring.template release<SYNC_PIECES>();
+        }
+        constexpr bool packed_relu = ACT == NERFX_ACT_RELU && P::PACKED_RELU && !SIGMA;
+        if (!packed_relu) {
+#pragma unroll
+            for (int t = 0; t < NG; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[grp][t][r] = activate<PREC, ACT>(acc[grp][t][r]);
+        }
+        if (SIGMA) {
+#pragma unroll
+            for (int t = 0; t < NG; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 w = NERFX_LDS_VEC(f32x4, sigw + 32 * (grp * NG + t) + 8 * g + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dot = fmaf(acc[grp][t][4 * g + i], w[i], dot);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NG; ++t)
+#pragma unroll
+            for (int s = 0; s < P::UPT; ++s) {
+                const typename P::Frag f = P::from_acc(acc[grp][t], s);
+                hout[(grp * NG + t) * P::UPT + s] = packed_relu ? P::relu(f) : f;
+            }
+    }
+    return dot;
+}
+
 // HD > 0 fixes the number of layers per trunk half at compile time (with the skip
 // connection on): the block body is then straight-line code, which hipcc allocates without
 // the loop-carried copies of the activation fragments that the runtime-depth form (HD = 0)
@@ -722,7 +820,10 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         // ---- fc_1 then fc_2; fc_2's first layer optionally sees [phi_x | h] (model.py:71-73).
         // Layer 0 writes A; the remaining 2 hd - 1 trunk layers alternate A -> B, B -> A, so the
         // last one always lands in B.
-        if (last == 0) dot = linear<PREC, RG, ACT, BIGENC, WT, 0, true, STASH, TRAIN>(ring, cst, h, A, B, true, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[0], a.tape_ex_tile);
+        // (fixed-depth bf16 inference with wide encoders reads the encoder-major stream)
+        constexpr bool ENCMAJOR = BIGENC && HD > 0 && !TRAIN && PREC == NERFX_PREC_BF16;
+        if constexpr (ENCMAJOR) linear_encmajor<RG, ACT, WT, 0, false>(ring, cst, h, B, A, enc, sigw, st);
+        else if (last == 0) dot = linear<PREC, RG, ACT, BIGENC, WT, 0, true, STASH, TRAIN>(ring, cst, h, A, B, true, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[0], a.tape_ex_tile);
         else linear<PREC, RG, ACT, BIGENC, WT, 0, false, STASH, TRAIN>(ring, cst, h, B, A, true, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[0], a.tape_ex_tile);
         const int skip = resid ? hd : -1;                          // the layer that sees phi_x again
         auto refresh = [&](int li) {                               // register-resident encodings only
@@ -736,9 +837,11 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
 #pragma unroll
         for (; li + 1 <= last; li += 2) {
             refresh(li);
-            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN, S_WT>(ring, cst + li * BIAS_STRIDE, h, A, B, li == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[li]);
+            if (ENCMAJOR && li == skip) { if constexpr (ENCMAJOR) linear_encmajor<RG, ACT, WT, WT, false>(ring, cst + li * BIAS_STRIDE, h, A, B, enc, sigw, st); }
+            else linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN, S_WT>(ring, cst + li * BIAS_STRIDE, h, A, B, li == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[li]);
             refresh(li + 1);
-            linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN, S_WT>(ring, cst + (li + 1) * BIAS_STRIDE, h, B, A, li + 1 == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[li + 1]);
+            if (ENCMAJOR && li + 1 == skip) { if constexpr (ENCMAJOR) linear_encmajor<RG, ACT, WT, WT, false>(ring, cst + (li + 1) * BIAS_STRIDE, h, B, A, enc, sigw, st); }
+            else linear<PREC, RG, ACT, BIGENC, WT, WT, false, STASH, TRAIN, S_WT>(ring, cst + (li + 1) * BIAS_STRIDE, h, B, A, li + 1 == skip, enc, sigw, st, nullptr, stash, zt, a.tape_z_tile[li + 1]);
         }
         if (last > 0) {
             refresh(last);
@@ -766,7 +869,8 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
                 for (int u = 0; u < ENC_BLOCK; ++u)
                     if (u < a.ed_units) tape.store_enc(a.tape_ed_tile, u, h, enc.cached[u]);
             }
-            linear<PREC, RG, ACT, BIGENC, RT, WT, false, false, TRAIN, S_WT>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li], a.tape_ed_tile);
+            if constexpr (ENCMAJOR) linear_encmajor<RG, ACT, RT, WT, false>(ring, cst + li * BIAS_STRIDE, h, A, B, enc, sigw, st);
+            else linear<PREC, RG, ACT, BIGENC, RT, WT, false, false, TRAIN, S_WT>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li], a.tape_ed_tile);
             ++li;
             // ---- rgb.2 + widened sigmoid (model.py:54, activations.py:18-20) ----------------
             f32x16 out;

@@ -9,7 +9,8 @@ namespace nerfx {
 
 int wgrad_tasks_create(nerfx_model* m);             // mlp_wgrad.hip
 
-int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
+int make_plan(const nerfx_model_desc_t& d, int layout, ModelPlan& p) {
+    const int prec = layout_prec(layout);
     NERFX_REQUIRE(d.width >= 16 && d.width <= 256 && d.width % 16 == 0,
                   "width %d unsupported (16..256, multiple of 16)", d.width);
     NERFX_REQUIRE(d.depth >= 2 && d.depth % 2 == 0 && d.depth <= 16, "depth %d unsupported (even, 2..16)", d.depth);
@@ -46,6 +47,7 @@ int make_plan(const nerfx_model_desc_t& d, int prec, ModelPlan& p) {
         }
         L.in_dim = L.enc_cols + L.chain_dim;
         L.group = group_tiles(prec, L.n_tiles);
+        L.enc_major = layout == NERFX_STREAM_ENCMAJOR && L.enc_units > 0;
         L.enc_seg = L.enc_units / enc_block(prec) * pad_to_piece(enc_block(prec) * L.group);   // block-wise padding
         L.chain_seg = pad_to_piece(L.chain_tiles * units_per_tile(prec) * L.group);
         L.unit0 = unit;
@@ -96,13 +98,24 @@ __device__ __forceinline__ void pack_layer(const float* __restrict__ W, const La
     for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < n_slices; s += (int64_t)gridDim.x * 256) {
         const int lane = (int)(s & 63);
         const int64_t unit = s >> 6;
-        const int grp = (int)(unit / group_units);
+        int grp = (int)(unit / group_units);
         int in_group = (int)(unit - (int64_t)grp * group_units);
+        const int block_units = pad_to_piece(EB * L.group);          // ENC_BLOCK k-units of one group, padded
+        if (L.enc_major) {                                          // [chunk][group][block] ... then [group][chained]
+            const int n_groups = L.n_tiles / L.group, enc_total = n_groups * L.enc_seg;
+            if (unit < enc_total) {
+                const int chunk = (int)unit / (n_groups * block_units), rem = (int)unit - chunk * n_groups * block_units;
+                grp = rem / block_units;
+                in_group = chunk * block_units + rem % block_units;
+            } else {
+                grp = ((int)unit - enc_total) / L.chain_seg;
+                in_group = L.enc_seg + ((int)unit - enc_total) % L.chain_seg;
+            }
+        }
         const bool enc = in_group < L.enc_seg;
         int ku, t;                                                  // [k-unit][tile in group]
         bool live;
         if (enc) {                                                  // ENC_BLOCK k-units per padded block
-            const int block_units = pad_to_piece(EB * L.group);
             const int eb = in_group / block_units, within = in_group - eb * block_units;
             ku = eb * EB + within / L.group;
             t = within % L.group;
@@ -203,6 +216,13 @@ static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipSt
         hipLaunchKernelGGL(pack_streams_kernel<NERFX_LAYOUT_M16>, dim3(64, p.n_layers), dim3(256), 0, stream,
                            m->plans_dev[NERFX_LAYOUT_M16], p.n_layers, src, m->stream_dev[NERFX_LAYOUT_M16], nullptr);
     }
+    if ((mask >> NERFX_PREC_BF16 & 1) && m->has_encmajor) {         // the bf16 inference stream of the wide-encoder kernel
+        const ModelPlan& p = m->plan[NERFX_STREAM_ENCMAJOR];
+        PackSources src{};
+        for (int li = 0; li < p.n_layers; ++li) src.w[li] = tensors[tensor_index(p, li, false)];
+        hipLaunchKernelGGL(pack_streams_kernel<NERFX_PREC_BF16>, dim3(64, p.n_layers), dim3(256), 0, stream,
+                           m->plans_dev[NERFX_STREAM_ENCMAJOR], p.n_layers, src, m->stream_dev[NERFX_STREAM_ENCMAJOR], nullptr);
+    }
     for (int prec = 0; prec < 2; ++prec) {
         if (!(mask >> prec & 1)) continue;
         const ModelPlan& p = m->plan[prec];
@@ -248,6 +268,7 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
     for (int prec = 0; prec < N_LAYOUTS; ++prec)
         if (int e = make_plan(*desc, prec, m->plan[prec])) { delete m; return e; }
     m->has_m16 = m16_supported(*desc);
+    m->has_encmajor = encmajor_supported(*desc);
     m->n_tensors = 2 + 2 * desc->depth + 8;
     if (n_tensors != m->n_tensors) {
         const int want = m->n_tensors;
@@ -256,7 +277,7 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
     }
     hipError_t e = hipGetDevice(&m->device);
     for (int prec = 0; prec < N_LAYOUTS && e == hipSuccess; ++prec)
-        if (prec != NERFX_LAYOUT_M16 || m->has_m16)
+        if (m->has_layout(prec))
             e = hipMalloc(&m->stream_dev[prec], (size_t)m->plan[prec].total_units * UNIT_BYTES);
     for (int prec = 0; prec < 2 && e == hipSuccess; ++prec)
         e = hipMalloc(&m->stream_bwd_dev[prec], (size_t)m->plan[prec].bwd_units * UNIT_BYTES);
@@ -266,7 +287,7 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
         return fail(e == hipErrorOutOfMemory ? NERFX_E_NOMEM : NERFX_E_HIP, "model allocation failed: %s", hipGetErrorString(e));
     }
     for (int prec = 0; prec < N_LAYOUTS && e == hipSuccess; ++prec) {   // the layer plans the pack kernel reads
-        if (prec == NERFX_LAYOUT_M16 && !m->has_m16) continue;
+        if (!m->has_layout(prec)) continue;
         const ModelPlan& p = m->plan[prec];
         LayerPlan all[2 * MAX_LAYERS];
         for (int li = 0; li < p.n_layers + p.n_bwd; ++li) all[li] = li < p.n_layers ? p.layer[li] : p.bwd[li - p.n_layers];
