@@ -181,11 +181,12 @@ __device__ __forceinline__ void linear16(PhasedRing& ring, lds_floats_t bias, in
         __builtin_amdgcn_s_setprio(3);
 #define NERFX_C c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1], c[3][0], c[3][1], M16_A_ARGS(a)
 #define NERFX_B(k0) hin.f[k0][0], hin.f[k0][1], hin.f[k0 + 1][0], hin.f[k0 + 1][1], hin.f[k0 + 2][0], hin.f[k0 + 2][1], hin.f[k0 + 3][0], hin.f[k0 + 3][1]
+        Frag16 sb[2][2];                                            // stash operands as loaded (unused here)
         if constexpr (CK == 0) {
-            m16_run8_stash_first_last(NERFX_C, p[0], stash, lane16);
+            m16_run8_stash_first_last(NERFX_C, p[0], sb[0][0], sb[0][1], sb[1][0], sb[1][1], stash, lane16);
         } else {
             constexpr int E = ENC_UNITS / PIECE_UNITS;                   // pieces in front of the chained ones
-            if constexpr (ENC == M16_ENC_STASH) m16_run8_stash_first_out(NERFX_C, p[0], p[1], stash, lane16);
+            if constexpr (ENC == M16_ENC_STASH) m16_run8_stash_first_out(NERFX_C, p[0], p[1], sb[0][0], sb[0][1], sb[1][0], sb[1][1], stash, lane16);
             if constexpr (ENC == M16_ENC_REGS) m16_run8_first_out(NERFX_C, p[0], p[1], encr[0][0], encr[0][1], encr[1][0], encr[1][1]);
             if constexpr (ENC == M16_ENC_NONE) m16_run16_first_out(NERFX_C, p[0], p[1], p[2], NERFX_B(0));
             else m16_run16_out(NERFX_C, p[E], p[E + 1], p[E + 2], NERFX_B(0));
@@ -233,8 +234,60 @@ __device__ __forceinline__ void linear16(PhasedRing& ring, lds_floats_t bias, in
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef NERFX_DIAG_SLEEP                         // timing diagnostic: is the phase between two runs on the critical path?
+        __builtin_amdgcn_s_sleep(NERFX_DIAG_SLEEP);
+#endif
         st.mark(ST_HEADS);
     }
+}
+
+// Layer 0: sixteen output tiles on the encoder's two k-units alone, as ONE segment of 32 units and
+// one phase.  Nothing is chained in, so the registers that hold a chained layer's input carry the
+// accumulators of all sixteen tiles; taken four tiles at a time like the other layers, its four
+// runs of 16 MFMAs would each last as long as the partner's (much longer) phase between two runs.
+template <int ACT>
+__device__ __forceinline__ void linear16_first(PhasedRing& ring, lds_floats_t bias, int q, Act16& hout, Stamps& st, uint32_t stash) {
+    constexpr int NT = 16, UNITS = NT * M16_ENC_KU;
+    f32x4 c[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) c[t][0] = c[t][1] = NERFX_LDS_VEC(f32x4, bias + 16 * t + 4 * q);
+    uint32_t p[UNITS / PIECE_UNITS];
+#pragma unroll
+    for (int k = 0; k < UNITS / PIECE_UNITS; ++k) p[k] = ring.piece_ptr(k * PIECE_UNITS);
+    const uint32_t lane16 = (uint32_t)ring.lane * 16u;
+    Frag16 a[M16_LOOKAHEAD], b[2][2];
+    st.mark(ST_EPILOGUE);
+    PhasedRing::landed();
+    st.mark(ST_ACQUIRE);
+    __builtin_amdgcn_s_setprio(3);
+#define NERFX_C4(t0) c[t0][0], c[t0][1], c[t0 + 1][0], c[t0 + 1][1], c[t0 + 2][0], c[t0 + 2][1], c[t0 + 3][0], c[t0 + 3][1], M16_A_ARGS(a)
+    m16_run8_stash_first_out(NERFX_C4(0), p[0], p[1], b[0][0], b[0][1], b[1][0], b[1][1], stash, lane16);
+    m16_run8_out(NERFX_C4(4), p[1], p[2], b[0][0], b[0][1], b[1][0], b[1][1]);
+    m16_run8_out(NERFX_C4(8), p[2], p[3], b[0][0], b[0][1], b[1][0], b[1][1]);
+    m16_run8_last(NERFX_C4(12), p[3], b[0][0], b[0][1], b[1][0], b[1][1]);
+#undef NERFX_C4
+    __builtin_amdgcn_s_setprio(0);
+    st.mark(ST_RUN);
+    ring.template finish<UNITS>();
+    constexpr bool packed_relu = ACT == NERFX_ACT_RELU;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t == 0) ring.refill(0);
+        if (t == 8) ring.refill(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!packed_relu) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[t][s][r] = activate<NERFX_PREC_BF16, ACT>(c[t][s][r]);
+        }
+        if (t & 1) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) hout.f[t / 2][s] = m16_from_acc<packed_relu>(c[t - 1][s], c[t][s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    st.mark(ST_HEADS);
 }
 
 template <int ACT, int HD>
@@ -311,7 +364,7 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
         float dot[2] = {0.0f, 0.0f};
         // ---- fc_1 then fc_2; fc_2's first layer sees [phi_x | h] (model.py:71-73).  Layer 0
         // writes A; the remaining 2 HD - 1 trunk layers alternate A -> B, B -> A and end in B.
-        linear16<ACT, 16, 0, false, M16_ENC_STASH>(ring, cst, q, B, A, sigw, dot, st, stash, encr);
+        linear16_first<ACT>(ring, cst, q, A, st, stash);
 #pragma unroll
         for (int li = 1; li + 1 <= LAST - 1; li += 2) {
             if (li == HD) linear16<ACT, 16, M16_KU, false, M16_ENC_STASH>(ring, cst + li * BIAS_STRIDE, q, A, B, sigw, dot, st, stash, encr);

@@ -68,22 +68,23 @@ def emit(name, params, decl, lines, outs, ins):
 
 
 def gen_run(n, first, carry_out, stash_b=False):
-    """n units.  `first`: the block opens a phase -- it requests its first LOOKAHEAD A operands
-    (and, with `stash_b`, its B operands from the wave's LDS stash at stash + (2 k + s) KiB), then
-    meets the phase barrier, then runs; otherwise the A operands are in flight on entry, requested
-    by the block before it.  B operands of the other blocks are registers b<k><s>."""
+    """n units.  `first`: the block opens a phase -- it requests its first LOOKAHEAD A operands,
+    then meets the phase barrier, then runs; otherwise the A operands are in flight on entry,
+    requested by the block before it.  With `stash_b` (first blocks only) the block reads its B
+    operands from the wave's LDS stash at stash + (2 k + s) KiB into b<k><s>, which the caller may
+    hand to the blocks that follow; the B operands of the other blocks are registers b<k><s>."""
     assert first or not stash_b
     pieces, kus = n // 8, n // TILES
     lg = Lgkm() if first else Lgkm([("a", i) for i in range(LOOKAHEAD)])
     rd = lambda i: f"ds_read_b128 %[a{i % LOOKAHEAD}], %[p{i // 8}] offset:{(i % 8) * 1024}"
     lines = []
+    if stash_b:
+        lines.append("v_add_u32 %[q], %[stash], %[lane16]")
+        for k in range(kus):
+            for s in (0, 1):
+                lines.append(f"ds_read_b128 %[b{k}{s}], %[q] offset:{(2 * k + s) * 1024}")
+                lg.read(("b", k, s))
     if first:
-        if stash_b:
-            lines.append("v_add_u32 %[q], %[stash], %[lane16]")
-            for k in range(kus):
-                for s in (0, 1):
-                    lines.append(f"ds_read_b128 %[b{k}{s}], %[q] offset:{(2 * k + s) * 1024}")
-                    lg.read(("b", k, s))
         for i in range(LOOKAHEAD):
             lines.append(rd(i))
             lg.read(("a", i))
@@ -114,8 +115,8 @@ def gen_run(n, first, carry_out, stash_b=False):
     ins = [f'[p{j}] "v"(p{j})' for j in range(pieces)] + (['[pn] "v"(pn)'] if carry_out else [])
     decl = ""
     if stash_b:
-        params += ["uint32_t stash", "uint32_t lane16"]
-        decl = f"    bf16x8 {', '.join(bnames)};\n    uint32_t q;\n"
+        params += [f"bf16x8& {b}" for b in bnames] + ["uint32_t stash", "uint32_t lane16"]
+        decl = "    uint32_t q;\n"
         outs += [f'[{b}] "=&v"({b})' for b in bnames] + ['[q] "=&v"(q)']
         ins += ['[stash] "s"(stash)', '[lane16] "v"(lane16)']
     else:
@@ -131,7 +132,9 @@ print("// p*: LDS byte address of each piece for this lane (pn: first piece of t
 print("// b<k><s>: B operand of k-unit k, block s.")
 print(f"#define M16_LOOKAHEAD {LOOKAHEAD}")
 print("#define M16_A_ARGS(a) " + ", ".join(f"a[{j}]" for j in range(LOOKAHEAD)))
-print(gen_run(8, True, False, stash_b=True))     # layer 0: encoder segment alone
+print(gen_run(8, True, False, stash_b=True))     # an encoder segment alone
+print(gen_run(8, False, True))                   # layer 0 (all sixteen tiles in one phase): middle blocks
+print(gen_run(8, False, False))                  # layer 0: last block
 print(gen_run(8, True, True, stash_b=True))      # skip layer: encoder segment, chained segment follows
 print(gen_run(8, True, True))                    # rgb.0: encoder operands in registers, chained segment follows
 print(gen_run(16, True, True))                   # first half of a chained segment opening a phase
