@@ -317,6 +317,24 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
     // coordinates as the pair tables want them, in revolutions: v / 2 pi (positional), 2 pi v / 2 pi (Fourier)
     const float x_scale = x_positional ? P::ANGLE_UNIT : 1.0f, d_scale = d_positional ? P::ANGLE_UNIT : 1.0f;
 
+    // A block's inputs (sample position along the ray, origin, direction) are requested one block
+    // ahead, right after the previous block's have been unpacked: their HBM round trip then runs
+    // under a whole block of work instead of in front of the first layer.
+    struct Inputs { float t[2], o[2][3], d[2][3]; };
+    auto request = [&](uint32_t blk, Inputs& in) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t m = blk * (32 * WAVES) + wave * 32 + 16 * s + col;
+            const uint32_t mc = m < a.n_points ? m : a.n_points - 1;
+            const size_t r = a.t ? mc / a.n_samples : mc;           // ray.py:132 / :226: one origin / direction per ray
+            in.t[s] = a.t ? a.t[mc] : 0.0f;
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) { in.o[s][ax] = a.ro[3 * r + ax]; in.d[s][ax] = a.rd[3 * r + ax]; }
+        }
+    };
+    Inputs next;
+    request(blockIdx.x < a.n_blocks ? blockIdx.x : 0, next);
+
     Stamps st;
     st.start();
     for (uint32_t blk = blockIdx.x; blk < a.n_blocks; blk += gridDim.x) {
@@ -328,21 +346,24 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
         for (int s = 0; s < 2; ++s) {
             m[s] = blk * (32 * WAVES) + wave * 32 + 16 * s + col;
             valid[s] = m[s] < a.n_points;
-            const uint32_t mc = valid[s] ? m[s] : a.n_points - 1;
-            if (a.t) {                                              // ray.py:132 / :226
-                const uint32_t ray = mc / a.n_samples;
-                const float tt = a.t[mc];
-                dx[s] = a.rd[3 * ray]; dy[s] = a.rd[3 * ray + 1]; dz[s] = a.rd[3 * ray + 2];
-                px[s] = __fadd_rn(a.ro[3 * ray], __fmul_rn(dx[s], tt));
-                py[s] = __fadd_rn(a.ro[3 * ray + 1], __fmul_rn(dy[s], tt));
-                pz[s] = __fadd_rn(a.ro[3 * ray + 2], __fmul_rn(dz[s], tt));
+            dx[s] = next.d[s][0]; dy[s] = next.d[s][1]; dz[s] = next.d[s][2];
+            if (a.t) {
+                px[s] = __fadd_rn(next.o[s][0], __fmul_rn(dx[s], next.t[s]));
+                py[s] = __fadd_rn(next.o[s][1], __fmul_rn(dy[s], next.t[s]));
+                pz[s] = __fadd_rn(next.o[s][2], __fmul_rn(dz[s], next.t[s]));
             } else {
-                px[s] = a.ro[3 * (size_t)mc]; py[s] = a.ro[3 * (size_t)mc + 1]; pz[s] = a.ro[3 * (size_t)mc + 2];
-                dx[s] = a.rd[3 * (size_t)mc]; dy[s] = a.rd[3 * (size_t)mc + 1]; dz[s] = a.rd[3 * (size_t)mc + 2];
+                px[s] = next.o[s][0]; py[s] = next.o[s][1]; pz[s] = next.o[s][2];
             }
             // A non-finite input poisons every feature in the reference (model.py:68-78).
             const float probe = (px[s] + py[s] + pz[s]) + (colour ? (dx[s] + dy[s] + dz[s]) : 0.0f);
             poisoned[s] = !(fabsf(probe) <= 3.0e38f);
+        }
+        // (the values above are in registers of their own before the next request overwrites `next`)
+        asm volatile("" : "+v"(px[0]), "+v"(py[0]), "+v"(pz[0]), "+v"(dx[0]), "+v"(dy[0]), "+v"(dz[0]));
+        asm volatile("" : "+v"(px[1]), "+v"(py[1]), "+v"(pz[1]), "+v"(dx[1]), "+v"(dy[1]), "+v"(dz[1]));
+        {
+            const uint32_t ahead = blk + gridDim.x;
+            request(ahead < a.n_blocks ? ahead : blk, next);
         }
         st.mark(ST_PROLOGUE);
         // phi_x is consumed twice (layer 0 and the skip layer): its B operands are parked in the
