@@ -165,9 +165,12 @@ __device__ __forceinline__ void linear16(PhasedRing& ring, lds_floats_t bias, in
     constexpr int ENC_UNITS = ENC != M16_ENC_NONE ? 8 : 0, UNITS = ENC_UNITS + 4 * CK;
 #pragma unroll
     for (int grp = 0; grp < NT / 4; ++grp) {
-        f32x4 c[4][2];
+        // the biases are requested first and used last: their LDS round trip runs under the address
+        // arithmetic (left alone, hipcc sinks the reads to their use and waits for them there)
+        f32x4 bv[4], c[4][2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) c[t][0] = c[t][1] = NERFX_LDS_VEC(f32x4, bias + 16 * (grp * 4 + t) + 4 * q);
+        for (int t = 0; t < 4; ++t) bv[t] = NERFX_LDS_VEC(f32x4, bias + 16 * (grp * 4 + t) + 4 * q);
+        __builtin_amdgcn_sched_barrier(0);
         uint32_t p[UNITS / PIECE_UNITS];
 #pragma unroll
         for (int k = 0; k < UNITS / PIECE_UNITS; ++k) p[k] = ring.piece_ptr(k * PIECE_UNITS);
@@ -176,6 +179,9 @@ __device__ __forceinline__ void linear16(PhasedRing& ring, lds_floats_t bias, in
         st.mark(ST_EPILOGUE);
         PhasedRing::landed();
         st.mark(ST_ACQUIRE);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c[t][0] = c[t][1] = bv[t];
         // (the wave inside a run goes first on its SIMD: its partner's VALU work takes the slots
         // between the MFMAs)
         __builtin_amdgcn_s_setprio(3);
