@@ -189,14 +189,14 @@ __device__ __forceinline__ void linear16(PhasedRing& ring, lds_floats_t bias, in
 #define NERFX_B(k0) hin.f[k0][0], hin.f[k0][1], hin.f[k0 + 1][0], hin.f[k0 + 1][1], hin.f[k0 + 2][0], hin.f[k0 + 2][1], hin.f[k0 + 3][0], hin.f[k0 + 3][1]
         Frag16 sb[2][2];                                            // stash operands as loaded (unused here)
         if constexpr (CK == 0) {
-            m16_run8_stash_first_last(NERFX_C, p[0], sb[0][0], sb[0][1], sb[1][0], sb[1][1], stash, lane16);
+            m16_run8_stash_first_last(NERFX_C, p[0], sb[0][0], sb[0][1], sb[1][0], sb[1][1], stash, lane16, st);
         } else {
             constexpr int E = ENC_UNITS / PIECE_UNITS;                   // pieces in front of the chained ones
-            if constexpr (ENC == M16_ENC_STASH) m16_run8_stash_first_out(NERFX_C, p[0], p[1], sb[0][0], sb[0][1], sb[1][0], sb[1][1], stash, lane16);
-            if constexpr (ENC == M16_ENC_REGS) m16_run8_first_out(NERFX_C, p[0], p[1], encr[0][0], encr[0][1], encr[1][0], encr[1][1]);
-            if constexpr (ENC == M16_ENC_NONE) m16_run16_first_out(NERFX_C, p[0], p[1], p[2], NERFX_B(0));
-            else m16_run16_out(NERFX_C, p[E], p[E + 1], p[E + 2], NERFX_B(0));
-            m16_run16_last(NERFX_C, p[E + 2], p[E + 3], NERFX_B(4));
+            if constexpr (ENC == M16_ENC_STASH) m16_run8_stash_first_out(NERFX_C, p[0], p[1], sb[0][0], sb[0][1], sb[1][0], sb[1][1], stash, lane16, st);
+            if constexpr (ENC == M16_ENC_REGS) m16_run8_first_out(NERFX_C, p[0], p[1], encr[0][0], encr[0][1], encr[1][0], encr[1][1], st);
+            if constexpr (ENC == M16_ENC_NONE) m16_run16_first_out(NERFX_C, p[0], p[1], p[2], NERFX_B(0), st);
+            else m16_run16_out(NERFX_C, p[E], p[E + 1], p[E + 2], NERFX_B(0), st);
+            m16_run16_last(NERFX_C, p[E + 2], p[E + 3], NERFX_B(4), st);
         }
 #undef NERFX_C
 #undef NERFX_B
@@ -267,10 +267,10 @@ __device__ __forceinline__ void linear16_first(PhasedRing& ring, lds_floats_t bi
     st.mark(ST_ACQUIRE);
     __builtin_amdgcn_s_setprio(3);
 #define NERFX_C4(t0) c[t0][0], c[t0][1], c[t0 + 1][0], c[t0 + 1][1], c[t0 + 2][0], c[t0 + 2][1], c[t0 + 3][0], c[t0 + 3][1], M16_A_ARGS(a)
-    m16_run8_stash_first_out(NERFX_C4(0), p[0], p[1], b[0][0], b[0][1], b[1][0], b[1][1], stash, lane16);
-    m16_run8_out(NERFX_C4(4), p[1], p[2], b[0][0], b[0][1], b[1][0], b[1][1]);
-    m16_run8_out(NERFX_C4(8), p[2], p[3], b[0][0], b[0][1], b[1][0], b[1][1]);
-    m16_run8_last(NERFX_C4(12), p[3], b[0][0], b[0][1], b[1][0], b[1][1]);
+    m16_run8_stash_first_out(NERFX_C4(0), p[0], p[1], b[0][0], b[0][1], b[1][0], b[1][1], stash, lane16, st);
+    m16_run8_out(NERFX_C4(4), p[1], p[2], b[0][0], b[0][1], b[1][0], b[1][1], st);
+    m16_run8_out(NERFX_C4(8), p[2], p[3], b[0][0], b[0][1], b[1][0], b[1][1], st);
+    m16_run8_last(NERFX_C4(12), p[3], b[0][0], b[0][1], b[1][0], b[1][1], st);
 #undef NERFX_C4
     __builtin_amdgcn_s_setprio(0);
     st.mark(ST_RUN);
@@ -344,6 +344,7 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
     Stamps st;
     st.start();
     for (uint32_t blk = blockIdx.x; blk < a.n_blocks; blk += gridDim.x) {
+        st.phase = 0;
         // ---- this lane's two samples (all four lane groups hold the same two) ----------
         uint32_t m[2];
         bool valid[2], poisoned[2];
@@ -439,14 +440,17 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
             const lds_bytes_t w0 = (lds_bytes_t)(uintptr_t)ring.piece_ptr(0);
             PhasedRing::landed();
             __builtin_amdgcn_s_barrier();                           // this segment's phase: compiler-scheduled, 8 MFMAs
+            st.mark_wait(ST_ACQUIRE, 0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const Frag16 w = NERFX_LDS_VEC(bf16x8, w0 + k * UNIT_BYTES);
                 out[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, B.f[k][0], out[0], 0, 0, 0);
                 out[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, B.f[k][1], out[1], 0, 0, 0);
             }
-            __builtin_amdgcn_s_barrier();
             st.mark(ST_RUN);
+            __builtin_amdgcn_s_barrier();
+            st.mark_wait(ST_BARRIER, 1);
+            ++st.phase;
             ring.template finish<8>();
             ring.refill(0);
             ring.refill(1);                                         // (group 0's duty here is half of rgb.0's last slot: 5 chunks)

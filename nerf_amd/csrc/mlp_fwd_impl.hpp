@@ -64,8 +64,8 @@ struct MlpArgs {
 // Bucket b accumulates the s_memtime cycles a wave spends between mark(b') and mark(b).
 struct Stamps {
 #ifdef NERFX_STAMPS
-    unsigned long long last, sum[6];
-    __device__ __forceinline__ void start() { last = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 6; ++i) sum[i] = 0; }
+    unsigned long long last, sum[8];
+    __device__ __forceinline__ void start() { last = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 8; ++i) sum[i] = 0; }
     __device__ __forceinline__ void mark(int b) {
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -73,15 +73,22 @@ struct Stamps {
         __builtin_amdgcn_sched_barrier(0);
     }
     __device__ __forceinline__ void flush(unsigned long long* out, int lane) {
-        if (lane == 0 && out) for (int i = 0; i < 6; ++i) atomicAdd(out + i, sum[i]);
+        if (lane == 0 && out) for (int i = 0; i < 8; ++i) atomicAdd(out + i, sum[i]);
     }
+    // (kernels that cut their run blocks at the barriers book the waits there: kind 0 = the barrier that
+    // opens this wave's run, 1 = the one that closes it)
+    int phase = 0;
+    __device__ __forceinline__ void mark_wait(int bucket, int) { mark(bucket); }
 #else
     __device__ __forceinline__ void start() {}
     __device__ __forceinline__ void mark(int) {}
     __device__ __forceinline__ void flush(unsigned long long*, int) {}
+    __device__ __forceinline__ void mark_wait(int, int) {}
+    int phase = 0;
 #endif
 };
-enum { ST_PROLOGUE = 0, ST_ACQUIRE = 1, ST_RUN = 2, ST_EPILOGUE = 3, ST_HEADS = 4, ST_ENCODE = 5 };
+// (ST_BARRIER: the closing barrier of a run, booked apart by the kernels whose blocks can be cut there)
+enum { ST_PROLOGUE = 0, ST_ACQUIRE = 1, ST_RUN = 2, ST_EPILOGUE = 3, ST_HEADS = 4, ST_ENCODE = 5, ST_BARRIER = 6 };
 
 // ---- training tape -------------------------------------------------------------------------
 // Scratch in HBM shared by the training forward, the backward chain and the weight-gradient

@@ -55,14 +55,26 @@ ACC_OUTS = ", ".join(f'[{c}] "+v"({c})' for c in ACC)
 A_PARAMS = ", ".join(f"bf16x8& a{j}" for j in range(LOOKAHEAD))
 
 
-def emit(name, params, decl, lines, outs, ins):
-    body = "\n".join(f'        "{l}\\n\\t"' for l in lines)
-    return f"""__device__ __forceinline__ void {name}({params}) {{
-{decl}    asm volatile(
-{body}
-        : {outs}
-        : {ins}
-        : "memory");
+def emit(name, params, decl, parts, outs, ins):
+    """`parts` = (opening, body, closing) instruction lists.  The product build issues them as one
+    statement.  The stamps build (-DNERFX_STAMPS) cuts the statement at the two barriers and reads
+    the clock there, so that a run's own duration and the time spent waiting at each barrier are
+    booked apart; the clock read returns through lgkmcnt, hence the full wait in front of the body
+    (the counted waits inside stay valid: they only ever ask for less)."""
+    quote = lambda ls: "\n".join(f'        "{l}\\n\\t"' for l in ls)
+    opening, body, closing = parts
+    stmt = lambda ls, o=outs: f"    asm volatile(\n{quote(ls)}\n        : {o}\n        : {ins}\n        : \"memory\");\n"
+    later = outs.replace('"=&v"', '"+v"')          # what the opening has requested is an input of the rest
+    cut = ""
+    if opening:
+        cut += stmt(opening) + "    st.mark_wait(ST_ACQUIRE, 0);\n"
+    cut += stmt((["s_waitcnt lgkmcnt(0)"] if opening else []) + body, later if opening else outs) + "    st.mark(ST_RUN);\n"
+    if closing:
+        cut += stmt(closing, later) + "    st.mark_wait(ST_BARRIER, 1);\n    ++st.phase;\n"
+    return f"""__device__ __forceinline__ void {name}({params}, Stamps& st) {{
+{decl}#ifdef NERFX_STAMPS
+{cut}#else
+{stmt(opening + body + closing)}#endif
 }}
 """
 
@@ -77,7 +89,7 @@ def gen_run(n, first, carry_out, stash_b=False):
     pieces, kus = n // 8, n // TILES
     lg = Lgkm() if first else Lgkm([("a", i) for i in range(LOOKAHEAD)])
     rd = lambda i: f"ds_read_b128 %[a{i % LOOKAHEAD}], %[p{i // 8}] offset:{(i % 8) * 1024}"
-    lines = []
+    lines, opening = [], []
     if stash_b:
         lines.append("v_add_u32 %[q], %[stash], %[lane16]")
         for k in range(kus):
@@ -92,6 +104,7 @@ def gen_run(n, first, carry_out, stash_b=False):
         # completes in order) must be in place before the barrier publishes it
         lines.append(f"s_waitcnt lgkmcnt({len(lg.issued)})")
         lines.append("s_barrier")
+        opening, lines = lines, []
     for i in range(0, n, 2):
         w = lg.wait_for(("a", i), ("a", i + 1), ("b", i // TILES, 0), ("b", i // TILES, 1))
         if w:
@@ -106,8 +119,7 @@ def gen_run(n, first, carry_out, stash_b=False):
                 k = j + LOOKAHEAD - n
                 lines.append(f"ds_read_b128 %[a{k % LOOKAHEAD}], %[pn] offset:{k * 1024}")
                 lg.read(("n", k))
-    if not carry_out:
-        lines += ["s_barrier", "s_nop 11"]
+    closing = [] if carry_out else ["s_barrier", "s_nop 11"]
     bnames = [f"b{k}{s}" for k in range(kus) for s in (0, 1)]
     a_con = '"=&v"' if first else '"+v"'
     params = [ACC_PARAMS, A_PARAMS] + [f"uint32_t p{j}" for j in range(pieces)] + (["uint32_t pn"] if carry_out else [])
@@ -123,7 +135,7 @@ def gen_run(n, first, carry_out, stash_b=False):
         params += [f"const bf16x8& {b}" for b in bnames]
         ins += [f'[{b}] "v"({b})' for b in bnames]
     name = f"m16_run{n}" + ("_stash" if stash_b else "") + ("_first" if first else "") + ("_out" if carry_out else "_last")
-    return emit(name, ", ".join(params), decl, lines, ", ".join(outs), ", ".join(ins))
+    return emit(name, ", ".join(params), decl, (opening, lines, closing), ", ".join(outs), ", ".join(ins))
 
 
 print("// GENERATED by tools/gen_mlp_runs_m16.py -- do not edit.")

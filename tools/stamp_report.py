@@ -13,12 +13,13 @@ model = NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 6), 256, 4).cuda()
 h = ops.handle_for(model)
 B = 65536
 ro, rd = torch.rand(B, 3, device="cuda"), torch.rand(B, 3, device="cuda")
-names = ["prologue", "acquire (wait for own loads)", "mfma runs incl. both barriers", "epilogue + next run set-up", "heads / refill issue", "encode"]
+names = ["prologue", "wait for own loads + opening barrier", "mfma runs", "next run set-up", "conversion / refill issue / heads", "encode", "closing barrier", "-"]
+# (kernels whose run blocks are not cut at the barriers book both barriers under "mfma runs")
 for n, dens in ((64, True), (128, False)):
     t = torch.rand(B, n, device="cuda") * 4 + 2
     for prec in (1,):
         ops.mlp_rays(h, ro, rd, t, density_only=dens, prec=prec)
-        buf = torch.zeros(6, dtype=torch.int64, device="cuda")
+        buf = torch.zeros(8, dtype=torch.int64, device="cuda")
         lib.nerfx_debug_set_stamps(ctypes.c_void_p(buf.data_ptr()))
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); ops.mlp_rays(h, ro, rd, t, density_only=dens, prec=prec); b.record()
