@@ -658,3 +658,39 @@ def test_bf16_kernels_agree_with_each_other(ops, name):
     # and a part of the batch alone gives the same bits as inside the whole
     part, _ = ops.mlp_points(h, x[256 * 700:256 * 900 + 13], d[256 * 700:256 * 900 + 13], density_only=True, prec=_lib.PREC_BF16)
     assert torch.equal(part, out[1][0][256 * 700:256 * 900 + 13])
+
+
+WIDE_ENCODER_MODELS = {
+    # (phi_x, phi_d, width, depth, activation): which encoder is wider than the register cache of 64 slots
+    "x wide, d narrow": (("ff", 40, 4.0), ("ff", 8, 2.0), 256, 4, "ReLU"),
+    "both wide, deep": (("ff", 96, 6.0), ("ff", 48, 3.0), 256, 8, "LeakyReLU"),
+    "positional, 12 frequencies": (("pe", 12), ("pe", 4), 256, 4, "SiLU"),
+    "x narrow, d wide": (("pe", 6), ("ff", 80, 2.0), 192, 4, "ReLU"),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(WIDE_ENCODER_MODELS))
+def test_wide_encoder_stream_order(ops, name):
+    """bf16 inference of the 256-wide skip models with encoders beyond 64 slots reads a stream of its
+    own (a layer's encoder units first, chunk by chunk for all tile groups): hold it against the fp32
+    kernel of the same weights, which reads the plain order, for encoder sizes that leave the last
+    chunk partly empty, for either encoder being the wide one, several blocks per workgroup and a
+    ragged tail.  A unit packed to the wrong place shows up as an error of the size of the outputs."""
+    from nerf_amd import _lib
+    from nerf_amd.core import FourierFeatures, NeRF, PositionalEncoding
+    ex, ed, width, depth, act = WIDE_ENCODER_MODELS[name]
+    enc = lambda spec: PositionalEncoding(3, spec[1]) if spec[0] == "pe" else FourierFeatures(3, spec[1], spec[2])
+    torch.manual_seed(5)
+    model = NeRF(enc(ex), enc(ed), width, depth, getattr(torch.nn, act)).cuda()
+    h = ops.handle_for(model)
+    gen = torch.Generator().manual_seed(23)
+    M = 256 * 256 * 2 + 131
+    x = ((torch.rand(M, 3, generator=gen) * 2 - 1) * 1.5).cuda()
+    d = (torch.rand(M, 3, generator=gen) * 2 - 1).cuda()
+    s32, c32 = ops.mlp_points(h, x, d, prec=_lib.PREC_FP32)
+    s16, c16 = ops.mlp_points(h, x, d, prec=_lib.PREC_BF16)
+    sd, _ = ops.mlp_points(h, x, d, density_only=True, prec=_lib.PREC_BF16)
+    assert torch.equal(sd, s16), "density differs between the full and the density-only pass"
+    assert_close(c16.cpu(), c32.cpu(), rtol=0, atol=1e-2, what="rgb: bf16 vs fp32 kernel")
+    assert_close(s16.cpu(), s32.cpu(), rtol=3e-2, atol=1e-2, what="sigma: bf16 vs fp32 kernel")
