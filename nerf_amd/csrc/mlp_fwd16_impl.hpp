@@ -314,6 +314,9 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
     for (int i = tid; i < a.const_floats; i += 64 * WAVES) cst[i] = a.consts[i];
     PhasedRing::landed();                                           // this wave's share of the initial fill
     __syncthreads();
+#ifdef NERFX_DIAG_SOLO                           // timing diagnostic (wrong results): group 0 alone, how long is a run by itself?
+    if (ring.group == 1) return;
+#endif
     if (ring.group == 1) __builtin_amdgcn_s_barrier();              // half a step behind group 0, from here on
 
     const lds_floats_t sigw = cst + a.sigw_off;
