@@ -265,6 +265,7 @@ __device__ __forceinline__ void linear16_first(PhasedRing& ring, lds_floats_t bi
     st.mark(ST_EPILOGUE);
     PhasedRing::landed();
     st.mark(ST_ACQUIRE);
+    st.coarse(1);                                                   // (coarse marks: 1 = from a block's last run to the next block's first)
     __builtin_amdgcn_s_setprio(3);
 #define NERFX_C4(t0) c[t0][0], c[t0][1], c[t0 + 1][0], c[t0 + 1][1], c[t0 + 2][0], c[t0 + 2][1], c[t0 + 3][0], c[t0 + 3][1], M16_A_ARGS(a)
     m16_run8_stash_first_out(NERFX_C4(0), p[0], p[1], b[0][0], b[0][1], b[1][0], b[1][1], stash, lane16, st);
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
         }
         static_assert(LAST != HD, "the skip layer is never the last trunk layer (HD >= 2)");
         linear16<ACT, 16, M16_KU, true, M16_ENC_NONE>(ring, cst + LAST * BIAS_STRIDE, q, A, B, sigw, dot, st, stash, encr);
+        if (!colour) st.coarse(0);                                  // (coarse marks: 0 = from a block's first run to its last)
         // ---- density head (model.py:75, activations.py:33-35): lane groups 0 / 1 store blocks 0 / 1
         st.mark(ST_EPILOGUE);
         {
@@ -453,6 +455,7 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
             st.mark(ST_RUN);
             __builtin_amdgcn_s_barrier();
             st.mark_wait(ST_BARRIER, 1);
+            st.coarse(0);
             ++st.phase;
             ring.template finish<8>();
             ring.refill(0);

@@ -66,11 +66,27 @@ struct Stamps {
 #ifdef NERFX_STAMPS
     unsigned long long last, sum[8];
     __device__ __forceinline__ void start() { last = __builtin_amdgcn_s_memtime(); for (int i = 0; i < 8; ++i) sum[i] = 0; }
-    __device__ __forceinline__ void mark(int b) {
+    __device__ __forceinline__ void fine(int b) {
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long now = __builtin_amdgcn_s_memtime();
         sum[b] += now - last; last = now;
         __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void mark(int b) {
+#if NERFX_STAMPS != 2
+        fine(b);
+#else
+        (void)b;
+#endif
+    }
+    // NERFX_STAMPS=2: only the marks made with coarse() count (a handful per block: the clock reads
+    // of the fine marks cost about a tenth of the kernel's time and move what they measure).
+    __device__ __forceinline__ void coarse(int b) {
+#if NERFX_STAMPS == 2
+        fine(b);
+#else
+        (void)b;
+#endif
     }
     __device__ __forceinline__ void flush(unsigned long long* out, int lane) {
         if (lane == 0 && out) for (int i = 0; i < 8; ++i) atomicAdd(out + i, sum[i]);
@@ -82,6 +98,7 @@ struct Stamps {
 #else
     __device__ __forceinline__ void start() {}
     __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void coarse(int) {}
     __device__ __forceinline__ void flush(unsigned long long*, int) {}
     __device__ __forceinline__ void mark_wait(int, int) {}
     int phase = 0;

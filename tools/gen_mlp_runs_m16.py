@@ -72,7 +72,7 @@ def emit(name, params, decl, parts, outs, ins):
     if closing:
         cut += stmt(closing, later) + "    st.mark_wait(ST_BARRIER, 1);\n    ++st.phase;\n"
     return f"""__device__ __forceinline__ void {name}({params}, Stamps& st) {{
-{decl}#ifdef NERFX_STAMPS
+{decl}#if defined(NERFX_STAMPS) && NERFX_STAMPS != 2
 {cut}#else
 {stmt(opening + body + closing)}#endif
 }}
