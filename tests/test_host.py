@@ -169,23 +169,80 @@ def test_from_torchscript_reads_a_scripted_field(tmp_path):
     assert set(want) == set(got) and all(torch.equal(want[k], got[k]) for k in want)
 
 
+def _kernel_assembly(tmp_path, stem):
+    """The assembly of nerf_amd/csrc/<stem>.hip as the Makefile built it (kept beside the objects), else
+    compiled here with the Makefile's flags."""
+    import shutil
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    built = os.path.join(root, "nerf_amd", "csrc", "build", f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s")
+    if os.path.exists(built):
+        return built
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine and no assembly kept by the build")
+    asm = str(tmp_path / f"{stem}.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17", "-fPIC",
+                    os.path.join(root, "nerf_amd", "csrc", f"{stem}.hip"), "-o", asm], check=True, capture_output=True, timeout=900)
+    return asm
+
+
+def _run_checker(mode, asm, kernel):
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    return subprocess.run([sys.executable, os.path.join(root, "tools", "check_async_loads.py"), mode, asm, kernel],
+                          capture_output=True, text=True, timeout=300)
+
+
 def test_async_tape_loads_keep_their_registers(tmp_path):
     """The bf16 backward chain issues its tape loads from inline asm, which the compiler does not
     track: in the compiled assembly nothing may touch their destination registers before the
-    counted wait that precedes their use (tools/check_async_loads.py)."""
-    import shutil
-    import subprocess
-    import sys
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("no hipcc on this machine")
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-    src = os.path.join(root, "nerf_amd", "csrc", "mlp_bwd_bf16.hip")
-    asm = str(tmp_path / "mlp_bwd_bf16.s")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17",
-                    "-I", os.path.join(root, "include"), src, "-o", asm], check=True, capture_output=True, timeout=600)
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_async_loads.py"), asm, "mlp_bwd_kernel"],
-                         capture_output=True, text=True, timeout=120)
+    counted wait that precedes their use (tools/check_async_loads.py; the Makefile runs the same
+    check on every build)."""
+    out = _run_checker("tape", _kernel_assembly(tmp_path, "mlp_bwd_bf16"), "mlp_bwd_kernel")
     assert out.returncode == 0, out.stdout[-2000:]
-    checked = int(out.stdout.strip().splitlines()[-1].split()[0])
-    assert checked > 0, "the checker found no async loads: has the kernel changed?"
+
+
+def test_carried_operands_keep_their_registers(tmp_path):
+    """The 16x16x32 forward's run blocks request the first A operands of the block that follows:
+    between the two asm statements the compiler must leave those registers alone."""
+    out = _run_checker("carry", _kernel_assembly(tmp_path, "mlp_fwd16_bf16"), "mlp_fwd16_kernel")
+    assert out.returncode == 0, out.stdout[-2000:]
+
+
+def test_async_checker_sees_a_violation(tmp_path):
+    """The checker itself: a register of an in-flight load touched before the marked wait, an operand
+    carried between two asm statements touched in between, and a file with nothing to check."""
+    tape = """kern_a:
+	;;#ASMSTART
+	global_load_dwordx4 v[4:7], v[2:3], off
+	;;#ASMEND
+	s_waitcnt vmcnt(4)
+	v_mov_b32_e32 v9, v5
+	;;#ASMSTART
+	s_waitcnt vmcnt(1) ; async tape loads landed
+	;;#ASMEND
+	v_mov_b32_e32 v9, v5
+"""
+    carry = """kern_b:
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]
+	ds_read_b128 v[8:11], v20 offset:0
+	;;#ASMEND
+	v_add_u32_e32 v8, 1, v8
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]
+	;;#ASMEND
+"""
+    for mode, text, kernel in (("tape", tape, "kern_a"), ("carry", carry, "kern_b")):
+        path = tmp_path / f"{mode}.s"
+        path.write_text(text)
+        out = _run_checker(mode, str(path), kernel)
+        assert out.returncode == 1 and "1 violations" in out.stdout, out.stdout
+        path.write_text(text.replace("v_mov_b32_e32 v9, v5\n\t;;#ASMSTART\n\ts_waitcnt", "\t;;#ASMSTART\n\ts_waitcnt").replace("\tv_add_u32_e32 v8, 1, v8\n", ""))
+        out = _run_checker(mode, str(path), kernel)
+        assert out.returncode == 0, out.stdout
+    empty = tmp_path / "empty.s"
+    empty.write_text("kern_c:\n\tv_mov_b32_e32 v0, v1\n")
+    assert _run_checker("tape", str(empty), "kern_c").returncode == 2
