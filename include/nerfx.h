@@ -333,6 +333,11 @@ void nerfx_debug_set_stamps(unsigned long long* device_buffer);
  * v_mfma_f32_32x32x16_bf16 kernels instead (same arithmetic, other summation order), for A/B
  * timing and for tests that hold one kernel against the other.  Process-wide; default on. */
 void nerfx_debug_set_m16(int enable);
+/* No counterpart in the reference.  nerfx_pdf_sample with 64 coarse and 64 fine samples, no uniforms
+ * and only t_sorted requested (what the render paths ask for) runs on a kernel that takes four rays
+ * per wavefront; enable = 0 keeps it on the general one-ray-per-wavefront kernel (same bits), for A/B
+ * timing and for the test that holds the two against each other.  Process-wide; default on. */
+void nerfx_debug_set_k4_fast(int enable);
 
 #ifdef __cplusplus
 }

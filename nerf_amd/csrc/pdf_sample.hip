@@ -7,6 +7,8 @@
 #include "common.hpp"
 #include "philox.hpp"
 
+#include <atomic>
+
 namespace nerfx {
 
 constexpr int K4_MAX = 256;                       // max nc and max nf
@@ -228,6 +230,225 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
     }
 }
 
+// ---- the 64 + 64 case (the reference's configuration), four rays per wavefront ----------------
+// Sixteen lanes own a ray and each lane four consecutive samples, so every load and store is 16
+// bytes wide, the sums and scans run over 16 lanes plus a short serial part, and the scalar
+// bookkeeping of an iteration serves four rays: about a fifth of the wave-instructions per ray of
+// the one-ray-per-wavefront kernel above, with the same arithmetic in the same order (the cdf is
+// a sum of doubles that never rounds, the interpolation and the linspace are the same expressions),
+// so the outputs are the same bits.  Rays whose fine or coarse values are not ascending (NaNs,
+// unsorted input) are sorted by the same bitonic network as above.
+constexpr int K4F = 64;                            // nc = nf = 64
+
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+    return v;
+}
+// exclusive scan over the 16 lanes of a ray
+__device__ __forceinline__ double group16_excl_sum(double v, int l) {
+    double inc = v;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+        const double o = __shfl_up(inc, off, 16);
+        if (l >= off) inc += o;
+    }
+    return inc - v;
+}
+__device__ __forceinline__ int group16_excl_sum(int v, int l) {
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+        const int o = __shfl_up(inc, off, 16);
+        if (l >= off) inc += o;
+    }
+    return inc - v;
+}
+
+// #{k in [0, 63) : a[k] <= x} for the 63-entry cdf: six fixed steps, no branches
+__device__ __forceinline__ int upper_bound63(const float* a, float x) {
+    int lo = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) lo += a[lo + step - 1] <= x ? step : 0;
+    return lo;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __restrict__ t_c, const float* __restrict__ w_c,
+                                                              int64_t n_rays, const float* __restrict__ u_g, Rng rng,
+                                                              float* __restrict__ t_sorted) {
+    static_assert(MODE == 0, "ascending positions only: perturbed rays take the general kernel");
+    constexpr int N = K4F, NB = N - 1, NW = N - 2;
+    __shared__ __attribute__((aligned(16))) float s_cdf[4][N], s_bins[4][N], s_tc[4][N], s_out[4][2 * N];
+    __shared__ __attribute__((aligned(16))) int s_hist[4][N + 4];
+    const int lane = threadIdx.x, g = lane >> 4, l = lane & 15, i0 = 4 * l;
+    float* cdf = s_cdf[g];
+    float* bins = s_bins[g];
+    float* tc = s_tc[g];
+    float* out = s_out[g];
+    int* hist = s_hist[g];
+    using f4 = float4;
+    auto fetch = [&](int64_t ray4, f4& tv, f4& wv) {
+        const int64_t ray = min(ray4 + g, n_rays - 1);
+        tv = *reinterpret_cast<const f4*>(t_c + ray * N + i0);
+        wv = *reinterpret_cast<const f4*>(w_c + ray * N + i0);
+    };
+    f4 t_cur, w_cur, t_nxt = {}, w_nxt = {};
+    const int64_t first = (int64_t)blockIdx.x * 4, stride = (int64_t)gridDim.x * 4;
+    if (first < n_rays) fetch(first, t_cur, w_cur);
+    asm volatile("" : "+v"(t_cur.x), "+v"(t_cur.y), "+v"(t_cur.z), "+v"(t_cur.w), "+v"(w_cur.x), "+v"(w_cur.y), "+v"(w_cur.z), "+v"(w_cur.w));
+    if (first + stride < n_rays) fetch(first + stride, t_nxt, w_nxt);
+    for (int64_t ray4 = first; ray4 < n_rays; ray4 += stride) {
+        const int64_t ray = ray4 + g;
+        const float tq[4] = {t_cur.x, t_cur.y, t_cur.z, t_cur.w}, wq[4] = {w_cur.x, w_cur.y, w_cur.z, w_cur.w};
+        // -- pdf and cdf (ray.py:161-164, :220): interior weights + 1e-5, normalised, summed ----
+        float wi[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + e;
+            wi[e] = (i >= 1 && i <= NW) ? __fadd_rn(wq[e], 1e-5f) : 0.f;
+        }
+        // (the one-ray kernel adds its 64 lane values in a butterfly; here four values are added in
+        // the lane first: both orders round differently only if the total itself is inexact, and the
+        // total only scales the pdf -- it is formed the same way as there to give the same bits)
+        float total;
+        {
+            // lane value order of the butterfly above: partial sums of lanes whose indices differ in
+            // the low bits first.  Reproduce it: bring the 64 values into that order.
+            *reinterpret_cast<f4*>(out + i0) = f4{wi[0], wi[1], wi[2], wi[3]};
+            wave_sync();
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = out[l + 16 * e];                  // value i = l + 16 e
+            // xor 32, 16 (between the four values of a lane), then 8, 4, 2, 1 (between lanes)
+            float a = (v[0] + v[2]) + (v[1] + v[3]);
+            total = group16_sum(a);
+            wave_sync();
+        }
+        double d[4], run = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i0 + e;
+            const float pdf = (i >= 1 && i <= NW) ? wi[e] / total : 0.f;
+            run += (double)pdf;
+            d[e] = run;
+        }
+        const double before = group16_excl_sum(run, l);
+        float cv[4], bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cv[e] = (float)(before + d[e]);                // cdf[i], i = i0 + e (cdf[0] = 0)
+        const float t_next = __shfl_down(tq[0], 1, 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = __fmul_rn(0.5f, __fadd_rn(tq[e], e < 3 ? tq[e + 1] : t_next));
+        *reinterpret_cast<f4*>(cdf + i0) = f4{cv[0], cv[1], cv[2], cv[3]};
+        *reinterpret_cast<f4*>(bins + i0) = f4{bv[0], bv[1], bv[2], bv[3]};
+        *reinterpret_cast<f4*>(tc + i0) = t_cur;
+        *reinterpret_cast<int4*>(hist + i0) = int4{0, 0, 0, 0};
+        if (l == 0) hist[N] = 0;
+        wave_sync();
+        // -- inverse cdf (ray.py:166-186) --------------------------------------------------
+        float tp[4];
+        int guess[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = i0 + e;
+            const float u = linspace_at(0.f, 1.f, N, j);
+            const int idx = upper_bound63(cdf, u);
+            static_assert(NB == 63, "the fixed-step search covers 63 entries");
+            const int below = max(idx - 1, 0), above = min(idx, NW);
+            const float cb = cdf[below], ca = cdf[above], bb = bins[below], ba = bins[above];
+            float den = __fsub_rn(ca, cb);
+            den = den < 1e-5f ? 1.0f : den;
+            const float frac = __fsub_rn(u, cb) / den;
+            tp[e] = __fadd_rn(bb, __fmul_rn(frac, __fsub_rn(ba, bb)));
+            guess[e] = idx;
+        }
+        // -- the next rays' inputs take over; the ones after them are requested ---------------
+        const f4 t_mine = t_cur;
+        t_cur = t_nxt; w_cur = w_nxt;
+        asm volatile("" : "+v"(t_cur.x), "+v"(t_cur.y), "+v"(t_cur.z), "+v"(t_cur.w), "+v"(w_cur.x), "+v"(w_cur.y), "+v"(w_cur.z), "+v"(w_cur.w));
+        if (ray4 + 2 * stride < n_rays) fetch(ray4 + 2 * stride, t_nxt, w_nxt);
+        // -- merge (ray.py:223) ----------------------------------------------------------------
+        const float tm[4] = {t_mine.x, t_mine.y, t_mine.z, t_mine.w};
+        const float tp_next = __shfl_down(tp[0], 1, 16);
+        bool bad = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool last = l == 15 && e == 3;
+            bad |= !last && !(tp[e] <= (e < 3 ? tp[e + 1] : tp_next));
+            bad |= !last && !(tm[e] <= (e < 3 ? tm[e + 1] : t_next));
+        }
+        const bool unsorted = (__ballot(bad) >> (16 * g)) & 0xFFFFull;
+        if (!unsorted) {
+            // fine sample j goes to j + #{i : tc[i] <= tp[j]} (a rank next to its bin index), coarse
+            // sample i to i + #{j : rank_j <= i} (a histogram of the ranks and a running sum)
+            // The rank lies next to the bin index (the sample was interpolated between the mid points
+            // around tc[idx]): three neighbours settle it without a loop unless values tie or round
+            // across a neighbour, which the loops then finish.
+            int rank[4];
+            bool settled = true;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = tp[e];
+                const int r0 = min(guess[e], N - 1);
+                const float lo = tc[max(r0 - 1, 0)], mid = tc[r0], hi = tc[min(r0 + 1, N - 1)];
+                int r = r0 + (mid <= v ? 1 : 0);                          // #{i <= r0 : tc[i] <= v} if tc[r0 - 1] <= v
+                const bool ok = (r0 == 0 || lo <= v) && (mid > v || r0 + 1 >= N || hi > v);
+                settled &= ok;
+                rank[e] = r;
+            }
+            if (__builtin_expect(!settled, 0)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = tp[e];
+                    int r = rank[e];
+                    while (r < N && tc[r] <= v) ++r;
+                    while (r > 0 && tc[r - 1] > v) --r;
+                    rank[e] = r;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                out[i0 + e + rank[e]] = tp[e];
+                atomicAdd(&hist[rank[e]], 1);
+            }
+            wave_sync();
+            const int4 hq = *reinterpret_cast<const int4*>(hist + i0);
+            int c[4] = {hq.x, hq.x + hq.y, hq.x + hq.y + hq.z, hq.x + hq.y + hq.z + hq.w};
+            const int carry = group16_excl_sum(c[3], l);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[i0 + e + carry + c[e]] = tm[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = tm[e], b = tp[e];
+                out[i0 + e] = a == a ? a : INFINITY;                        // NaNs sort last
+                out[N + i0 + e] = b == b ? b : INFINITY;
+            }
+            wave_sync();
+            for (int k = 2; k <= 2 * N; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = l; i < 2 * N; i += 16) {
+                        const int partner = i ^ j;
+                        if (partner > i) {
+                            const float a = out[i], b = out[partner];
+                            const bool up = (i & k) == 0;
+                            if ((a > b) == up) { out[i] = b; out[partner] = a; }
+                        }
+                    }
+                    wave_sync();
+                }
+        }
+        wave_sync();
+        if (ray < n_rays) {
+            float* dst = t_sorted + ray * (2 * N) + 8 * l;
+            reinterpret_cast<f4*>(dst)[0] = *reinterpret_cast<const f4*>(out + 8 * l);
+            reinterpret_cast<f4*>(dst)[1] = *reinterpret_cast<const f4*>(out + 8 * l + 4);
+        }
+        wave_sync();
+    }
+}
+
 __global__ __launch_bounds__(256) void searchsorted_right_kernel(
     const float* __restrict__ cdf, const float* __restrict__ u, int64_t n_rows, int n_cdf, int n_u,
     int64_t* __restrict__ idx) {
@@ -238,6 +459,11 @@ __global__ __launch_bounds__(256) void searchsorted_right_kernel(
     }
 }
 
+// Diagnostic switch: the 64 + 64 case can be kept on the general kernel (A/B timing, and the test that
+// holds the two kernels against each other bit for bit).
+static std::atomic<int> g_k4_fast{1};
+static bool k4_fast_enabled() { return g_k4_fast.load(std::memory_order_relaxed) != 0; }
+
 // `u` = the caller's uniforms, else `rng.on` = draw them in the kernel, else linspace(0, 1, nf).
 int pdf_sample_launch(const float* t_c, const float* w_c, int64_t n_rays, int nc, int nf, const float* u, const Rng& rng,
                       float* t_sorted, float* cdf, int64_t* idx, float* t_pdf, hipStream_t stream) {
@@ -246,6 +472,12 @@ int pdf_sample_launch(const float* t_c, const float* w_c, int64_t n_rays, int nc
     NERFX_REQUIRE(nf >= 1 && nf <= K4_MAX, "nf %d out of range [1, %d]", nf, K4_MAX);
     if (n_rays == 0) return 0;
     NERFX_REQUIRE(t_c && w_c && t_sorted, "t_c / w_c / t_sorted is NULL");
+    const bool aligned = (((uintptr_t)t_c | (uintptr_t)w_c | (uintptr_t)t_sorted) & 15) == 0;
+    if (nc == K4F && nf == K4F && !u && !rng.on && !cdf && !idx && !t_pdf && aligned && k4_fast_enabled()) {
+        const int grid4 = (int)std::min<int64_t>((n_rays + 3) / 4, 256 * 32);
+        hipLaunchKernelGGL(pdf_sample_64x64_kernel<0>, dim3(grid4), dim3(64), 0, stream, t_c, w_c, n_rays, u, rng, t_sorted);
+        return launch_status("pdf_sample_64x64_kernel");
+    }
     const int grid = (int)std::min<int64_t>(n_rays, 256 * 32);
     const int longest = std::max(nc, nf);
     using Kernel = void (*)(const float*, const float*, int64_t, int, int, const float*, Rng, float*, float*, int64_t*, float*);
@@ -260,6 +492,8 @@ int pdf_sample_launch(const float* t_c, const float* w_c, int64_t n_rays, int nc
 }  // namespace nerfx
 
 using namespace nerfx;
+
+extern "C" void nerfx_debug_set_k4_fast(int enable) { g_k4_fast.store(enable ? 1 : 0, std::memory_order_relaxed); }
 
 extern "C" int nerfx_pdf_sample(const float* t_c, const float* w_c, int64_t n_rays, int nc, int nf,
                                 const float* u, float* t_sorted, float* cdf, int64_t* idx, float* t_pdf,

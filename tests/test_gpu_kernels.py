@@ -694,3 +694,33 @@ def test_wide_encoder_stream_order(ops, name):
     assert torch.equal(sd, s16), "density differs between the full and the density-only pass"
     assert_close(c16.cpu(), c32.cpu(), rtol=0, atol=1e-2, what="rgb: bf16 vs fp32 kernel")
     assert_close(s16.cpu(), s32.cpu(), rtol=3e-2, atol=1e-2, what="sigma: bf16 vs fp32 kernel")
+
+
+def test_k4_four_rays_per_wavefront_same_bits(ops):
+    """The 64 + 64 production form of the hierarchical sampler runs on a kernel of its own (four rays
+    per wavefront): bit for bit the general kernel's result, on smooth and spiky weights, zero
+    weights, ties, ray counts that leave a wavefront partly empty, and on rows that must take the
+    sorting path (descending coarse values, NaN weights)."""
+    from nerf_amd import _lib
+    gen = torch.Generator().manual_seed(3)
+    for B in (1, 3, 4, 5, 1021, 65536 + 2):
+        t_c = torch.sort(torch.rand(B, 64, generator=gen) * 4 + 2, dim=-1).values
+        w_c = torch.rand(B, 64, generator=gen)
+        w_c[B // 3:] = w_c[B // 3:] ** 8                              # spiky
+        w_c[-1] = 0.0                                                 # all weights zero
+        if B > 4:
+            t_c[1, 10:20] = t_c[1, 10]                                # ties
+            t_c[2] = t_c[2].flip(0)                                   # descending: sorting path
+            w_c[3, 5] = float("nan")
+            w_c[4, 7] = float("inf")
+        t_c, w_c = t_c.cuda(), w_c.cuda()
+        out = {}
+        try:
+            for fast in (1, 0):
+                _lib.lib.nerfx_debug_set_k4_fast(fast)
+                out[fast] = ops.pdf_sample(t_c, w_c, 64)
+        finally:
+            _lib.lib.nerfx_debug_set_k4_fast(1)
+        a, b = out[1].cpu(), out[0].cpu()
+        same = (a == b) | (a.isnan() & b.isnan())
+        assert bool(same.all()), f"B={B}: {int((~same).sum())} values differ, first at {(~same).nonzero()[0].tolist()}"
