@@ -278,11 +278,57 @@ __device__ __forceinline__ int upper_bound63(const float* a, float x) {
     return lo;
 }
 
+// The value of lane l ^ M of the row, M = 1, 2, 4, 8.
+template <int M>
+__device__ __forceinline__ float row_xor(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    if constexpr (M == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    else return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(b, (M << 10) | 0x1F));                               // bit mode: xor M
+}
+// 64 values, four per lane of a 16-lane row (value p = 4 l + e), into ascending order of p: the
+// bitonic network, exchanges inside a lane by register, between lanes by DPP / swizzle.
+__device__ __forceinline__ void group16_sort64(float (&k)[4], int l) {
+    auto inside = [&](int j, int kk) {                          // partner p ^ j, j = 1 or 2
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f = e ^ j;
+            if (f > e) {
+                const bool up = kk >= 64 ? true : (((4 * l + e) & kk) == 0);
+                const float lo = fminf(k[e], k[f]), hi = fmaxf(k[e], k[f]);
+                k[e] = up ? lo : hi;
+                k[f] = up ? hi : lo;
+            }
+        }
+    };
+    auto across = [&](auto m_tag, int kk) {                     // partner lane l ^ M, same e
+        constexpr int M = decltype(m_tag)::value;
+        const bool lower = (l & M) == 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float o = row_xor<M>(k[e]);
+            const bool up = kk >= 64 ? true : (((4 * l + e) & kk) == 0);
+            k[e] = (lower == up) ? fminf(k[e], o) : fmaxf(k[e], o);
+        }
+    };
+    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
+    inside(1, 2);
+    inside(2, 4); inside(1, 4);
+    across(I1{}, 8); inside(2, 8); inside(1, 8);
+    across(I2{}, 16); across(I1{}, 16); inside(2, 16); inside(1, 16);
+    across(I4{}, 32); across(I2{}, 32); across(I1{}, 32); inside(2, 32); inside(1, 32);
+    across(I8{}, 64); across(I4{}, 64); across(I2{}, 64); across(I1{}, 64); inside(2, 64); inside(1, 64);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __restrict__ t_c, const float* __restrict__ w_c,
                                                               int64_t n_rays, const float* __restrict__ u_g, Rng rng,
                                                               float* __restrict__ t_sorted) {
-    static_assert(MODE == 0, "ascending positions only: perturbed rays take the general kernel");
+    // MODE = where the inverse-CDF positions come from: 0 linspace(0, 1, 64), 1 the caller's uniforms,
+    // 2 drawn in the kernel.  Uniforms are SORTED first: the result is the sorted union of coarse and
+    // fine values whatever the order of the uniforms (ray.py:223), and ascending uniforms give
+    // ascending fine values, which merge by rank instead of being sorted with the coarse ones.
     constexpr int N = K4F, NB = N - 1, NW = N - 2;
     __shared__ __attribute__((aligned(16))) float s_cdf[4][N], s_bins[4][N], s_tc[4][N], s_out[4][2 * N];
     __shared__ __attribute__((aligned(16))) int s_hist[4][N + 4];
@@ -299,6 +345,7 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
         wv = *reinterpret_cast<const f4*>(w_c + ray * N + i0);
     };
     f4 t_cur, w_cur, t_nxt = {}, w_nxt = {};
+    (void)u_g; (void)rng;
     const int64_t first = (int64_t)blockIdx.x * 4, stride = (int64_t)gridDim.x * 4;
     if (first < n_rays) fetch(first, t_cur, w_cur);
     asm volatile("" : "+v"(t_cur.x), "+v"(t_cur.y), "+v"(t_cur.z), "+v"(t_cur.w), "+v"(w_cur.x), "+v"(w_cur.y), "+v"(w_cur.z), "+v"(w_cur.w));
@@ -352,12 +399,26 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
         if (l == 0) hist[N] = 0;
         wave_sync();
         // -- inverse cdf (ray.py:166-186) --------------------------------------------------
+        float uq[4];
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) uq[e] = linspace_at(0.f, 1.f, N, i0 + e);
+        } else {
+            if constexpr (MODE == 1) {
+                const f4 uv = *reinterpret_cast<const f4*>(u_g + min(ray, n_rays - 1) * N + i0);
+                uq[0] = uv.x; uq[1] = uv.y; uq[2] = uv.z; uq[3] = uv.w;
+            } else {
+                const Philox4 b = rng_block(rng, (uint64_t)(min(ray, n_rays - 1) * N + i0) >> 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) uq[e] = rng_to_float(b.w[e]);
+            }
+            group16_sort64(uq, l);
+        }
         float tp[4];
         int guess[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int j = i0 + e;
-            const float u = linspace_at(0.f, 1.f, N, j);
+            const float u = uq[e];
             const int idx = upper_bound63(cdf, u);
             static_assert(NB == 63, "the fixed-step search covers 63 entries");
             const int below = max(idx - 1, 0), above = min(idx, NW);
@@ -478,9 +539,10 @@ int pdf_sample_launch(const float* t_c, const float* w_c, int64_t n_rays, int nc
     if (n_rays == 0) return 0;
     NERFX_REQUIRE(t_c && w_c && t_sorted, "t_c / w_c / t_sorted is NULL");
     const bool aligned = (((uintptr_t)t_c | (uintptr_t)w_c | (uintptr_t)t_sorted) & 15) == 0;
-    if (nc == K4F && nf == K4F && !u && !rng.on && !cdf && !idx && !t_pdf && aligned && k4_fast_enabled()) {
+    if (nc == K4F && nf == K4F && !cdf && !idx && !t_pdf && aligned && (((uintptr_t)u & 15) == 0) && k4_fast_enabled()) {
         const int grid4 = (int)std::min<int64_t>((n_rays + 3) / 4, 256 * 64);       // (8,192 workgroups: 3 % slower)
-        hipLaunchKernelGGL(pdf_sample_64x64_kernel<0>, dim3(grid4), dim3(64), 0, stream, t_c, w_c, n_rays, u, rng, t_sorted);
+        auto kern = u ? pdf_sample_64x64_kernel<1> : (rng.on ? pdf_sample_64x64_kernel<2> : pdf_sample_64x64_kernel<0>);
+        hipLaunchKernelGGL(kern, dim3(grid4), dim3(64), 0, stream, t_c, w_c, n_rays, u, rng, t_sorted);
         return launch_status("pdf_sample_64x64_kernel");
     }
     const int grid = (int)std::min<int64_t>(n_rays, 256 * 32);

@@ -699,8 +699,9 @@ def test_wide_encoder_stream_order(ops, name):
 def test_k4_four_rays_per_wavefront_same_bits(ops):
     """The 64 + 64 production form of the hierarchical sampler runs on a kernel of its own (four rays
     per wavefront): bit for bit the general kernel's result, on smooth and spiky weights, zero
-    weights, ties, ray counts that leave a wavefront partly empty, and on rows that must take the
-    sorting path (descending coarse values, NaN weights)."""
+    weights, ties, ray counts that leave a wavefront partly empty, on rows that must take the
+    sorting path (descending coarse values, NaN weights), and with the caller's uniforms, which it sorts
+    before it uses them."""
     from nerf_amd import _lib
     gen = torch.Generator().manual_seed(3)
     for B in (1, 3, 4, 5, 1021, 65536 + 2):
@@ -714,13 +715,19 @@ def test_k4_four_rays_per_wavefront_same_bits(ops):
             w_c[3, 5] = float("nan")
             w_c[4, 7] = float("inf")
         t_c, w_c = t_c.cuda(), w_c.cuda()
-        out = {}
-        try:
-            for fast in (1, 0):
-                _lib.lib.nerfx_debug_set_k4_fast(fast)
-                out[fast] = ops.pdf_sample(t_c, w_c, 64)
-        finally:
-            _lib.lib.nerfx_debug_set_k4_fast(1)
-        a, b = out[1].cpu(), out[0].cpu()
-        same = (a == b) | (a.isnan() & b.isnan())
-        assert bool(same.all()), f"B={B}: {int((~same).sum())} values differ, first at {(~same).nonzero()[0].tolist()}"
+        # without uniforms (linspace), and with the caller's: unsorted, with repeats, 0 and values next to 1
+        u = torch.rand(B, 64, generator=gen)
+        u[:, 5] = u[:, 9]
+        u[0, 0], u[0, 1] = 0.0, 1.0 - 2.0 ** -24
+        for uniforms in (None, u.cuda()):
+            out = {}
+            try:
+                for fast in (1, 0):
+                    _lib.lib.nerfx_debug_set_k4_fast(fast)
+                    out[fast] = ops.pdf_sample(t_c, w_c, 64, uniforms)
+            finally:
+                _lib.lib.nerfx_debug_set_k4_fast(1)
+            a, b = out[1].cpu(), out[0].cpu()
+            same = (a == b) | (a.isnan() & b.isnan())
+            assert bool(same.all()), (f"B={B}, uniforms {'given' if uniforms is not None else 'none'}: "
+                                      f"{int((~same).sum())} values differ, first at {(~same).nonzero()[0].tolist()}")
