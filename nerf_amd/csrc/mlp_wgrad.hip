@@ -201,6 +201,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WTask* __restrict__
         const uint32_t off = voff + (uint32_t)(c - c0) * (uint32_t)(O::CHUNK * 32 * sizeof(T));   // within this split
 #pragma unroll
         for (int s = 0; s < 2 * WG_SIDE; ++s) staged[s] = *reinterpret_cast<const V*>(base[s] + off);
+#ifdef WGRAD_DIAG_NO_LOAD                        // timing diagnostic (wrong results): what does the rest cost without the tape?
+#pragma unroll
+        for (int s = 0; s < 2 * WG_SIDE; ++s) staged[s] = *reinterpret_cast<const V*>(base[s] + voff);
+#endif
     };
     auto commit = [&](int buf) {
         lds_bytes_t dst = (lds_bytes_t)smem + buf * (2 * WG_SIDE * TILE_BYTES) + tid * 16;
@@ -211,7 +215,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WTask* __restrict__
                 const V a = O::template act<ACT>(v);
                 v = act_on[s] ? a : v;
             }
+#ifdef WGRAD_DIAG_NO_COMMIT                      // timing diagnostic (wrong results): no LDS stores (the values stay live)
+            asm volatile("" :: "v"(v));
+#else
             *reinterpret_cast<__attribute__((address_space(3))) V*>(dst + s * TILE_BYTES) = v;
+#endif
         }
     };
 
@@ -231,31 +239,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WTask* __restrict__
             for (int r = 0; r < 16; ++r) acc[o][n][r] = 0.0f;
     }
 
-    if (c0 < c1) { stage(c0); commit(0); }
-    __syncthreads();
-    for (int c = c0; c < c1; ++c) {
-        const int buf = (c - c0) & 1;
-        if (c + 1 < c1) stage(c + 1);
-        if (a_on[0] && b_on[0]) {                                   // wave-uniform: this wave has work
-            lds_bytes_t base = (lds_bytes_t)smem + buf * (2 * WG_SIDE * TILE_BYTES);
-            lds_bytes_t ta = base + oa * TILE_BYTES, tb = base + (WG_SIDE + ib) * TILE_BYTES;
-#pragma unroll 4
-            for (int kk = 0; kk < O::CHUNK / O::KSTEP; ++kk) {
-                const typename O::Frag a0 = O::fetch(ta, lane_off, kk), a1 = O::fetch(ta + TILE_BYTES, lane_off, kk);
-                const typename O::Frag b0 = O::fetch(tb, lane_off, kk), b1 = O::fetch(tb + TILE_BYTES, lane_off, kk);
-                O::mma(acc[0][0], a0, b0);
-                O::mma(acc[0][1], a0, b1);
-                O::mma(acc[1][0], a1, b0);
-                O::mma(acc[1][1], a1, b1);
-                if (do_bias) {
-                    O::mma(accb[0], a0, ones);
-                    O::mma(accb[1], a1, ones);
+    // The chunk loop exists twice, with and without the bias products, chosen once per wavefront
+    // (every wavefront meets the same barriers either way): no branch inside the multiply loop, and
+    // the operands of step kk + 1 are requested before the products of step kk are issued, so a
+    // wavefront's LDS latency runs under its own MFMAs instead of in front of them.
+    const bool has_work = a_on[0] && b_on[0];                       // wave-uniform
+    auto chunks = [&](auto bias_tag) {
+        constexpr bool BIAS = decltype(bias_tag)::value;
+        constexpr int KK = O::CHUNK / O::KSTEP;
+        if (c0 < c1) { stage(c0); commit(0); }
+        __syncthreads();
+        for (int c = c0; c < c1; ++c) {
+            const int buf = (c - c0) & 1;
+            if (c + 1 < c1) stage(c + 1);
+            if (has_work) {
+                lds_bytes_t base = (lds_bytes_t)smem + buf * (2 * WG_SIDE * TILE_BYTES);
+                lds_bytes_t ta = base + oa * TILE_BYTES, tb = base + (WG_SIDE + ib) * TILE_BYTES;
+                typename O::Frag f[2][4];
+                f[0][0] = O::fetch(ta, lane_off, 0); f[0][1] = O::fetch(ta + TILE_BYTES, lane_off, 0);
+                f[0][2] = O::fetch(tb, lane_off, 0); f[0][3] = O::fetch(tb + TILE_BYTES, lane_off, 0);
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    const int cur = kk & 1, nxt = cur ^ 1;
+                    if (kk + 1 < KK) {
+                        f[nxt][0] = O::fetch(ta, lane_off, kk + 1); f[nxt][1] = O::fetch(ta + TILE_BYTES, lane_off, kk + 1);
+                        f[nxt][2] = O::fetch(tb, lane_off, kk + 1); f[nxt][3] = O::fetch(tb + TILE_BYTES, lane_off, kk + 1);
+                    }
+                    O::mma(acc[0][0], f[cur][0], f[cur][2]);
+                    O::mma(acc[0][1], f[cur][0], f[cur][3]);
+                    O::mma(acc[1][0], f[cur][1], f[cur][2]);
+                    O::mma(acc[1][1], f[cur][1], f[cur][3]);
+                    if constexpr (BIAS) {
+                        O::mma(accb[0], f[cur][0], ones);
+                        O::mma(accb[1], f[cur][1], ones);
+                    }
                 }
             }
+            if (c + 1 < c1) commit(buf ^ 1);
+            __syncthreads();
         }
-        if (c + 1 < c1) commit(buf ^ 1);
-        __syncthreads();
-    }
+    };
+    if (do_bias) chunks(std::true_type{});
+    else chunks(std::false_type{});
     // products with absent (aliased) tiles are never stored
     float* dst = partial + ((size_t)vid * TASK_TILES) * 1024 + lane * 16;
 #pragma unroll
