@@ -158,8 +158,29 @@ struct Tape {
         T* p = at(tile, 16 * h);
         if constexpr (BF16) {
             auto pk = [](float lo, float hi) { uint32_t r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; };
-            reinterpret_cast<u32x4*>(p)[0] = u32x4{pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7])};
-            reinterpret_cast<u32x4*>(p)[1] = u32x4{pk(v[8], v[9]), pk(v[10], v[11]), pk(v[12], v[13]), pk(v[14], v[15])};
+            u32x4 p0 = u32x4{pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7])};
+            u32x4 p1 = u32x4{pk(v[8], v[9]), pk(v[10], v[11]), pk(v[12], v[13]), pk(v[14], v[15])};
+#ifdef NERFX_TAPE_STORE_SPLIT
+            // a lane's 32 bytes as its own two 16-byte stores: each instruction fills every other
+            // 16 bytes of the wavefront's 2 KiB
+            reinterpret_cast<u32x4*>(p)[0] = p0;
+            reinterpret_cast<u32x4*>(p)[1] = p1;
+#else
+            // The two halves trade places between the 16-lane rows first (row 1 of the first half
+            // with row 0 of the second, row 3 with row 2), so that the first store carries all 64
+            // bytes of the wavefront's samples 0..15 and the second those of samples 16..31: two
+            // contiguous 1 KiB stores.  Row r of a store then holds, for sample 16 * store + lane % 16,
+            // the piece (lane half r / 2, 16-byte half r % 2) -- the same bytes at the same addresses.
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(p0[e], p1[e], false, false);
+                p0[e] = sw[0]; p1[e] = sw[1];
+            }
+            const int k = (int)((threadIdx.x >> 4) & 1);                // this lane's row is an odd one
+            T* q = p - 16 * k * 32 + 8 * k;                             // sample m - 16 k, position 16 h + 8 k
+            *reinterpret_cast<u32x4*>(q) = p0;
+            *reinterpret_cast<u32x4*>(q + 16 * 32) = p1;
+#endif
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) reinterpret_cast<f32x4*>(p)[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
