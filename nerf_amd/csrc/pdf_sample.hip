@@ -506,10 +506,10 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
                 }
         }
         wave_sync();
-        if (ray < n_rays) {
-            float* dst = t_sorted + ray * (2 * N) + 8 * l;
-            reinterpret_cast<f4*>(dst)[0] = *reinterpret_cast<const f4*>(out + 8 * l);
-            reinterpret_cast<f4*>(dst)[1] = *reinterpret_cast<const f4*>(out + 8 * l + 4);
+        if (ray < n_rays) {                                         // each store of a ray's 16 lanes is 256 contiguous bytes
+            float* dst = t_sorted + ray * (2 * N) + 4 * l;
+            *reinterpret_cast<f4*>(dst) = *reinterpret_cast<const f4*>(out + 4 * l);
+            *reinterpret_cast<f4*>(dst + N) = *reinterpret_cast<const f4*>(out + N + 4 * l);
         }
         wave_sync();
     }
