@@ -489,6 +489,7 @@ class _RenderTrainFunction(torch.autograd.Function):
         ctx.param_meta = [(tuple(p.shape), p.requires_grad) for p in params]
         ctx.save_for_backward(rd, t)
         ctx.mark_non_differentiable(t)
+        ctx.set_materialize_grads(False)         # outputs the loss does not use arrive as None, not as zero fills
         return t, w, depth, rgb_map
 
     @staticmethod
