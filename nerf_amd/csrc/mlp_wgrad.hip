@@ -200,8 +200,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WTask* __restrict__
     auto stage = [&](int c) {
         const uint32_t off = voff + (uint32_t)(c - c0) * (uint32_t)(O::CHUNK * 32 * sizeof(T));   // within this split
 #pragma unroll
-#ifdef WGRAD_NT_LOADS
+#if defined(WGRAD_NT_LOADS)
         for (int s = 0; s < 2 * WG_SIDE; ++s) staged[s] = __builtin_nontemporal_load(reinterpret_cast<const V*>(base[s] + off));
+#elif defined(WGRAD_DIAG_HALF_LOADS)             // timing diagnostic (wrong results): only the gradient tiles are fetched
+        for (int s = 0; s < 2 * WG_SIDE; ++s) staged[s] = *reinterpret_cast<const V*>(base[s % WG_SIDE] + off);
 #else
         for (int s = 0; s < 2 * WG_SIDE; ++s) staged[s] = *reinterpret_cast<const V*>(base[s] + off);
 #endif
