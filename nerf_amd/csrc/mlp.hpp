@@ -151,7 +151,8 @@ struct ModelPlan {
     int n_layers;       // 2*hd + 3
     LayerPlan layer[MAX_LAYERS];
     int64_t trunk_units;   // stream units up to and including the last trunk layer
-    int64_t total_units;   // whole stream
+    int64_t total_units;   // whole stream (M16 layout: with the padding of m16_static, if any)
+    int m16_static;        // M16 layout: both stream lengths are whole ring lengths (see M16_RING_UNITS)
     // const block (floats): [layer biases | sigma w | sigma b | table x | table d]
     int sigw_off, sigb_off, tabx_off, tabd_off, const_floats;
     // Backward stream: the input-gradient chain rgb.2 -> rgb.0 -> features -> trunk (last .. 1),
@@ -177,6 +178,18 @@ inline bool encmajor_supported(const nerfx_model_desc_t& d) {
     return d.width > 128 && d.width <= 256 && d.resid && (d.depth == 4 || d.depth == 8) &&
            (enc_units(d.enc_x_kind, d.enc_x_n, NERFX_PREC_BF16) > ENC_BLOCK || enc_units(d.enc_d_kind, d.enc_d_n, NERFX_PREC_BF16) > ENC_BLOCK);
 }
+// The M16 kernel's weight ring, in 1 KiB units.  A stream whose length is a whole number of ring
+// lengths puts every unit of a sample block at the same ring position in every block, which makes
+// all of the kernel's ring arithmetic compile-time constants (static mode).  The depth-4 streams fit:
+// 448 units up to the density head = 4 rings; 664 with the colour layers, padded to 672 = 6 rings.
+constexpr int M16_RING_UNITS = 112;
+constexpr int M16_STATIC_PAD = 8;               // padding units behind rgb.2 in static mode
+__host__ __device__ constexpr int m16_trunk_units(int hd) { return 32 + (2 * hd - 1) * 128 + 32; }
+__host__ __device__ constexpr int m16_total_units(int hd) { return m16_trunk_units(hd) + 128 + 80 + 8; }
+__host__ __device__ constexpr bool m16_static_depth(int hd) {
+    return m16_trunk_units(hd) % M16_RING_UNITS == 0 && (m16_total_units(hd) + M16_STATIC_PAD) % M16_RING_UNITS == 0;
+}
+static_assert(m16_static_depth(2), "the depth-4 model streams are whole ring lengths");
 // Models the M16 inference kernel takes: 129..256 wide, skip connection, depth 4 or 8, encoders
 // of at most 64 slots (positional up to 10 frequencies, Fourier up to 32 features).
 inline bool m16_supported(const nerfx_model_desc_t& d) {

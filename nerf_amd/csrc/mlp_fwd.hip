@@ -12,7 +12,7 @@ int launch_mlp_fp32_bigenc(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_bigenc_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
 int launch_mlp_fp32_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
-int launch_mlp_m16(int activ, int hd, const MlpArgs& a, hipStream_t s);
+int launch_mlp_m16(int activ, int hd, bool is_static, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_train(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_fp32_train(int activ, int wt, const MlpArgs& a, hipStream_t s);
 int launch_mlp_bf16_train_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s);
@@ -86,7 +86,7 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
         const ModelPlan& p16 = model->plan[NERFX_LAYOUT_M16];
         a.stream = (const char*)model->stream_dev[NERFX_LAYOUT_M16];
         a.n_pieces = (uint32_t)((rgb ? p16.total_units : p16.trunk_units) / PIECE_UNITS);
-        return launch_mlp_m16(p.desc.activ, p.hd, a, (hipStream_t)stream);
+        return launch_mlp_m16(p.desc.activ, p.hd, p16.m16_static != 0, a, (hipStream_t)stream);
     }
     // encoders that fit the kernels' register cache take the fast instantiations
     const bool big = a.ex_units > ENC_BLOCK || a.ed_units > ENC_BLOCK;

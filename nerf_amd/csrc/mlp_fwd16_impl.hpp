@@ -29,9 +29,10 @@
 // phase 2 s and by group 1 in phase 2 s + 1; after that group 1 refills the first half of its
 // slot and, one phase later, group 0 the second half (each wave a quarter of a half), with the
 // stream units that lie one ring length ahead.  A wave waits for its own loads before its next
-// barrier, so what was requested in phase p is visible to everybody from phase p + 1.  With a
-// ring of two maximal segments every unit of segment n has been requested by phase 2 n - 2 (its
-// first units, which are read ahead before the barrier) resp. 2 n - 1.
+// barrier, so what was requested in phase p is visible to everybody from phase p + 1.  A ring of
+// two maximal segments (80 units) is what this needs: every unit of segment n has then been
+// requested by phase 2 n - 2 (its first units, which are read ahead before the barrier) resp.
+// 2 n - 1; the ring is 112 units for the static mode below, which requests everything 32 units earlier.
 #pragma once
 #include "mlp_fwd_impl.hpp"
 
@@ -45,7 +46,7 @@ constexpr int M16_ENC_KU = 2;                   // k-units of an encoder (64 slo
 constexpr int M16_STASH_BYTES_PER_WAVE = M16_ENC_KU * 2 * UNIT_BYTES;
 static_assert(M16_ENC_KU == enc_block(M16), "encoder segment size");
 
-constexpr int M16_RING_UNITS = 80;              // two segments of 40 units
+static_assert(M16_RING_UNITS >= 80, "at least two segments of 40 units");
 static_assert(M16_RING_UNITS % PIECE_UNITS == 0, "a piece never straddles the end of the ring");
 
 struct PhasedRing {
@@ -81,6 +82,20 @@ struct PhasedRing {
         fill_ring = 0; fill_stream = 0; fill_chunks = 0;
         constexpr int CHUNKS = M16_RING_UNITS / CHUNK;
         for (int k = w; k < CHUNKS; k += RingBf16::WAVES) load_chunk(k * CHUNK, k * CHUNK);
+    }
+    // Static mode (stream length = whole ring lengths): at the top of every sample block the ring is
+    // in the same state, which is written down here as constants -- consumption back at unit 0 of
+    // ring and stream, and group 0 still owing the second half of the slot of the block's last
+    // segment (LAST_UNITS long, at the end of the stream).  Everything the block's phases derive
+    // from it (piece addresses, refill sources and targets, wrap-arounds) then folds at compile
+    // time.  In a workgroup's first block nothing is owed yet; refilling that half slot anyway
+    // rewrites ring units with the bytes the initial fill has put there.
+    template <uint32_t STREAM_UNITS, uint32_t LAST_UNITS>
+    __device__ __forceinline__ void restart() {
+        static_assert(STREAM_UNITS % M16_RING_UNITS == 0 && STREAM_UNITS >= 2 * M16_RING_UNITS, "whole ring lengths");
+        n_units = STREAM_UNITS;
+        cons = 0; cons_stream = 0;
+        prev_units = LAST_UNITS; prev_stream = STREAM_UNITS - LAST_UNITS; prev_cons = (STREAM_UNITS - LAST_UNITS) % M16_RING_UNITS;
     }
     // This wave's loads have landed (required before any barrier that publishes them).
     static __device__ __forceinline__ void landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -297,7 +312,10 @@ __device__ __forceinline__ void linear16_first(PhasedRing& ring, lds_floats_t bi
     st.mark(ST_HEADS);
 }
 
-template <int ACT, int HD>
+// MODE: 0 = ring positions tracked at run time (any stream length); static mode (see
+// PhasedRing::restart): 1 = up to the density head, 2 = with the colour layers.
+enum { M16_DYNAMIC = 0, M16_STATIC_DENSITY = 1, M16_STATIC_COLOUR = 2 };
+template <int ACT, int HD, int MODE>
 __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp_fwd16_kernel(const MlpArgs a) {
     using RG = RingBf16;
     using P = Prec<NERFX_PREC_BF16>;
@@ -321,7 +339,8 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
     if (ring.group == 1) __builtin_amdgcn_s_barrier();              // half a step behind group 0, from here on
 
     const lds_floats_t sigw = cst + a.sigw_off;
-    const bool colour = a.rgb != nullptr;
+    const bool colour = MODE == M16_DYNAMIC ? a.rgb != nullptr : MODE == M16_STATIC_COLOUR;
+    constexpr int RGB2_UNITS = 8 + (MODE == M16_STATIC_COLOUR ? M16_STATIC_PAD : 0);   // the padding rides with the last segment
     constexpr int LAST = 2 * HD - 1;                                // last trunk layer feeds the density head
     const bool x_positional = a.ex_kind == NERFX_ENC_POSITIONAL, d_positional = a.ed_kind == NERFX_ENC_POSITIONAL;
     // coordinates as the pair tables want them, in revolutions: v / 2 pi (positional), 2 pi v / 2 pi (Fourier)
@@ -349,6 +368,8 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
     st.start();
     for (uint32_t blk = blockIdx.x; blk < a.n_blocks; blk += gridDim.x) {
         st.phase = 0;
+        if constexpr (MODE == M16_STATIC_DENSITY) ring.template restart<m16_trunk_units(HD), 32>();
+        if constexpr (MODE == M16_STATIC_COLOUR) ring.template restart<m16_total_units(HD) + M16_STATIC_PAD, RGB2_UNITS>();
         // ---- this lane's two samples (all four lane groups hold the same two) ----------
         uint32_t m[2];
         bool valid[2], poisoned[2];
@@ -457,7 +478,7 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
             st.mark_wait(ST_BARRIER, 1);
             st.coarse(0);
             ++st.phase;
-            ring.template finish<8>();
+            ring.template finish<RGB2_UNITS>();
             ring.refill(0);
             ring.refill(1);                                         // (group 0's duty here is half of rgb.0's last slot: 5 chunks)
             if (q == 0) {                                           // rows 0..2 of the tile sit in lane group 0
@@ -480,10 +501,13 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // no LDS-DMA may outlive the workgroup
 }
 
-template <int ACT, int HD>
+template <int ACT, int HD, int MODE>
 static int launch_cfg16(const MlpArgs& a, hipStream_t stream) {
     using RG = RingBf16;
-    auto kern = mlp_fwd16_kernel<ACT, HD>;
+    auto kern = mlp_fwd16_kernel<ACT, HD, MODE>;
+    if (MODE == M16_STATIC_DENSITY) NERFX_REQUIRE(a.n_pieces * PIECE_UNITS == (uint32_t)m16_trunk_units(HD), "stream length %u", a.n_pieces * PIECE_UNITS);
+    if (MODE == M16_STATIC_COLOUR)
+        NERFX_REQUIRE(a.n_pieces * PIECE_UNITS == (uint32_t)(m16_total_units(HD) + M16_STATIC_PAD), "stream length %u", a.n_pieces * PIECE_UNITS);
     const size_t lds_bytes = (size_t)a.const_floats * sizeof(float) + (size_t)M16_RING_UNITS * UNIT_BYTES +
                              (size_t)RG::WAVES * M16_STASH_BYTES_PER_WAVE;
     NERFX_REQUIRE(lds_bytes <= 160 * 1024, "model needs %zu bytes of LDS per workgroup", lds_bytes);

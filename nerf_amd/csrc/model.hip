@@ -55,6 +55,12 @@ int make_plan(const nerfx_model_desc_t& d, int layout, ModelPlan& p) {
         if (li == 2 * p.hd - 1) p.trunk_units = unit;
     }
     p.total_units = unit;
+    p.m16_static = 0;
+    if (layout == NERFX_LAYOUT_M16 && m16_static_depth(p.hd) && p.trunk_units == m16_trunk_units(p.hd) &&
+        p.total_units == m16_total_units(p.hd)) {
+        p.m16_static = 1;
+        p.total_units += M16_STATIC_PAD;                            // never read by an MFMA, only carried through the ring
+    }
     // backward chain
     p.n_bwd = 2 * p.hd + 2;
     unit = 0;
@@ -279,6 +285,8 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
     for (int prec = 0; prec < N_LAYOUTS && e == hipSuccess; ++prec)
         if (m->has_layout(prec))
             e = hipMalloc(&m->stream_dev[prec], (size_t)m->plan[prec].total_units * UNIT_BYTES);
+    if (e == hipSuccess && m->has_m16)                              // (its padding units are never packed)
+        e = hipMemset(m->stream_dev[NERFX_LAYOUT_M16], 0, (size_t)m->plan[NERFX_LAYOUT_M16].total_units * UNIT_BYTES);
     for (int prec = 0; prec < 2 && e == hipSuccess; ++prec)
         e = hipMalloc(&m->stream_bwd_dev[prec], (size_t)m->plan[prec].bwd_units * UNIT_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&m->const_dev, (size_t)m->plan[0].const_floats * sizeof(float));
