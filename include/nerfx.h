@@ -88,8 +88,9 @@ int  nerfx_model_create(const nerfx_model_desc_t* desc /* host */,
                         void* stream, nerfx_model_t** out /* host */);
 int  nerfx_model_refresh(nerfx_model_t* model, const float* const* tensors, int n_tensors,
                          void* stream);
-/* The same for the packed copies of ONE precision (NERFX_PREC_*) plus the shared
- * constants: what a training loop that stays in one precision needs per step. */
+/* The same for the weights and biases of ONE precision (NERFX_PREC_*): what a training loop
+ * that stays in one precision needs per step.  The encoder tables (tensors[0], tensors[1]:
+ * buffers, not parameters) are NOT re-read; after changing those call nerfx_model_refresh. */
 int  nerfx_model_refresh_precision(nerfx_model_t* model, const float* const* tensors, int n_tensors,
                                    int precision, void* stream);
 void nerfx_model_destroy(nerfx_model_t* model);

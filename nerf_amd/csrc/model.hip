@@ -210,8 +210,10 @@ static int tensor_index(const ModelPlan& p, int li, bool bias) {
     return base + (bias ? 1 : 0);
 }
 
-// Packs the const block and the unit streams of the precisions in `mask` (bit NERFX_PREC_*).
-static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipStream_t stream) {
+// Packs the const block and the unit streams of the precisions in `mask` (bit NERFX_PREC_*);
+// `tables`: also the encoders' coefficient tables (buffers, not parameters: an optimizer step
+// never changes them).
+static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipStream_t stream, bool tables = true) {
     const ModelPlan& p0 = m->plan[0];
     const nerfx_model_desc_t& d = p0.desc;
     for (int i = 0; i < m->n_tensors; ++i) NERFX_REQUIRE(tensors[i] != nullptr, "tensor %d is NULL", i);
@@ -256,8 +258,10 @@ static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipSt
         hipLaunchKernelGGL(pack_pair_table_kernel, dim3((entries + 255) / 256), dim3(256), 0, stream, src, kind, n, entries,
                            m->const_dev + off);
     };
-    table(tensors[0], d.enc_x_kind, d.enc_x_n, p0.tabx_off);
-    table(tensors[1], d.enc_d_kind, d.enc_d_n, p0.tabd_off);
+    if (tables) {
+        table(tensors[0], d.enc_x_kind, d.enc_x_n, p0.tabx_off);
+        table(tensors[1], d.enc_d_kind, d.enc_d_n, p0.tabd_off);
+    }
     return launch_status("pack kernels");
 }
 
@@ -324,7 +328,7 @@ extern "C" int nerfx_model_refresh_precision(nerfx_model_t* m, const float* cons
     NERFX_REQUIRE(m && tensors, "NULL argument");
     NERFX_REQUIRE(n_tensors == m->n_tensors, "expected %d tensors, got %d", m->n_tensors, n_tensors);
     NERFX_REQUIRE(precision == NERFX_PREC_FP32 || precision == NERFX_PREC_BF16, "unknown precision %d", precision);
-    return pack_all(m, tensors, 1 << precision, (hipStream_t)stream);
+    return pack_all(m, tensors, 1 << precision, (hipStream_t)stream, false);
 }
 
 extern "C" void nerfx_model_destroy(nerfx_model_t* m) {

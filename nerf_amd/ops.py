@@ -231,8 +231,14 @@ class ModelHandle:
         stamp = self._current_stamp()
         if stamp != self._stamp[prec]:
             tensors, arr = self._gather()
+            # epoch + the two encoder tables: a change there (or an invalidate) re-packs everything
+            full = stamp[:3] != self._stamp[prec][:3]
             with torch.cuda.device(self.device):
-                check(lib.nerfx_model_refresh_precision(self._ptr, arr, len(tensors), prec, _stream()))
+                if full:
+                    check(lib.nerfx_model_refresh(self._ptr, arr, len(tensors), _stream()))
+                    self._stamp = [stamp, stamp]
+                else:
+                    check(lib.nerfx_model_refresh_precision(self._ptr, arr, len(tensors), prec, _stream()))
             self._stamp[prec] = stamp
         return self._ptr
 

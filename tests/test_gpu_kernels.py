@@ -601,6 +601,24 @@ def test_packed_weights_follow_every_kind_of_write(ops):
     assert_close(s2.cpu(), want, rtol=1e-5, atol=2e-6, what="sigma after two bias writes")
 
 
+def test_packed_encoder_tables_follow_their_buffers(ops):
+    """A per-step refresh re-packs weights and biases only; an in-place write to an encoder's
+    buffer (version counter moves) must still reach the packed coefficient tables."""
+    meta, g = load_golden("g3_mlp_student")
+    model = product_model(meta, g)
+    x, d = dev(g["rx"]), dev(g["rd"])
+    with torch.no_grad():
+        s0, c0 = model(x, d)
+        model.sigma[0].bias.add_(0.25)                       # weights-only refresh
+        s1, _ = model(x, d)
+        model.phi_x.freq_bands.mul_(0.5)                     # encoder table of x
+        s2, c2 = model(x, d)
+        model.phi_x.freq_bands.mul_(2.0)                     # and back (exact: powers of two)
+        s3, _ = model(x, d)
+    assert not torch.equal(s0, s1) and not torch.equal(s1, s2)
+    assert torch.equal(s1, s3), "restoring the buffer restores the output bit for bit"
+
+
 def test_bf16_density_head_keeps_tiny_densities(ops):
     """softplus(x - 1) for strongly negative x is e^(x-1), not 0 (reference activations.py:33-35
     uses log1p): with the last segment 1e10 long (ray.py:63) such a density still makes the last
