@@ -108,8 +108,10 @@ __global__ __launch_bounds__(64) void pdf_sample_kernel(
             }
         }
         if (lane == 0) unsorted = 0;
+        // neighbours first (1, 2, 4, ... 32): the four-rays-per-wavefront kernel below, whose lanes hold
+        // four consecutive values each, forms the same sums in the same order without leaving its registers
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        for (int off = 1; off < 64; off <<= 1) part += __shfl_xor(part, off, 64);
         const float total = part;
         wave_sync();
         double carry = 0.0;
@@ -330,8 +332,14 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
     // fine values whatever the order of the uniforms (ray.py:223), and ascending uniforms give
     // ascending fine values, which merge by rank instead of being sorted with the coarse ones.
     constexpr int N = K4F, NB = N - 1, NW = N - 2;
-    __shared__ __attribute__((aligned(16))) float s_cdf[4][N], s_bins[4][N], s_tc[4][N], s_out[4][2 * N];
-    __shared__ __attribute__((aligned(16))) int s_hist[4][N + 4];
+    // The four rays of a wavefront gather from their rows at about the same index at the same time (the
+    // fine samples, the bins and the ranks all ascend along the lanes), so rows that start 64 floats
+    // apart put all four on ONE of the 64 LDS banks.  Rows of 64 k + 1 floats shift ray g by g banks:
+    // the four use different banks whenever their indices agree modulo 4 (a lane's own four values are
+    // then only 4-byte aligned and move as pairs of dwords instead of 16 bytes).
+    __shared__ float s_cdf[4][N + 1], s_bins[4][N + 1], s_tc[4][N + 1], s_out[4][2 * N + 1];
+    __shared__ int s_hist[4][N + 1];
+    auto store4 = [](auto* p, auto a, auto b, auto c, auto d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; };
     const int lane = threadIdx.x, g = lane >> 4, l = lane & 15, i0 = 4 * l;
     float* cdf = s_cdf[g];
     float* bins = s_bins[g];
@@ -360,23 +368,11 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
             const int i = i0 + e;
             wi[e] = (i >= 1 && i <= NW) ? __fadd_rn(wq[e], 1e-5f) : 0.f;
         }
-        // (the one-ray kernel adds its 64 lane values in a butterfly; here four values are added in
-        // the lane first: both orders round differently only if the total itself is inexact, and the
-        // total only scales the pdf -- it is formed the same way as there to give the same bits)
-        float total;
-        {
-            // lane value order of the butterfly above: partial sums of lanes whose indices differ in
-            // the low bits first.  Reproduce it: bring the 64 values into that order.
-            *reinterpret_cast<f4*>(out + i0) = f4{wi[0], wi[1], wi[2], wi[3]};
-            wave_sync();
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = out[l + 16 * e];                  // value i = l + 16 e
-            // xor 32, 16 (between the four values of a lane), then 8, 4, 2, 1 (between lanes)
-            float a = (v[0] + v[2]) + (v[1] + v[3]);
-            total = group16_sum(a);
-            wave_sync();
-        }
+        // the total in the one-ray kernel's order: a butterfly over 64 values, neighbours first, i.e.
+        // a lane's four values, then the lanes of the ray at distances 1, 2, 4, 8 (the total only scales
+        // the pdf, but the same order gives the same bits as that kernel)
+        float total = (wi[0] + wi[1]) + (wi[2] + wi[3]);
+        total += row_xor<1>(total); total += row_xor<2>(total); total += row_xor<4>(total); total += row_xor<8>(total);
         double d[4], run = 0.0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -392,10 +388,10 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
         const float t_next = row_next(tq[0]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[e] = __fmul_rn(0.5f, __fadd_rn(tq[e], e < 3 ? tq[e + 1] : t_next));
-        *reinterpret_cast<f4*>(cdf + i0) = f4{cv[0], cv[1], cv[2], cv[3]};
-        *reinterpret_cast<f4*>(bins + i0) = f4{bv[0], bv[1], bv[2], bv[3]};
-        *reinterpret_cast<f4*>(tc + i0) = t_cur;
-        *reinterpret_cast<int4*>(hist + i0) = int4{0, 0, 0, 0};
+        store4(cdf + i0, cv[0], cv[1], cv[2], cv[3]);
+        store4(bins + i0, bv[0], bv[1], bv[2], bv[3]);
+        store4(tc + i0, tq[0], tq[1], tq[2], tq[3]);
+        store4(hist + i0, 0, 0, 0, 0);
         if (l == 0) hist[N] = 0;
         wave_sync();
         // -- inverse cdf (ray.py:166-186) --------------------------------------------------
@@ -479,8 +475,8 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
                 atomicAdd(&hist[rank[e]], 1);
             }
             wave_sync();
-            const int4 hq = *reinterpret_cast<const int4*>(hist + i0);
-            int c[4] = {hq.x, hq.x + hq.y, hq.x + hq.y + hq.z, hq.x + hq.y + hq.z + hq.w};
+            const int h0 = hist[i0], h1 = hist[i0 + 1], h2 = hist[i0 + 2], h3 = hist[i0 + 3];
+            int c[4] = {h0, h0 + h1, h0 + h1 + h2, h0 + h1 + h2 + h3};
             const int carry = group16_excl_sum(c[3]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) out[i0 + e + carry + c[e]] = tm[e];
@@ -508,8 +504,8 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
         wave_sync();
         if (ray < n_rays) {                                         // each store of a ray's 16 lanes is 256 contiguous bytes
             float* dst = t_sorted + ray * (2 * N) + 4 * l;
-            *reinterpret_cast<f4*>(dst) = *reinterpret_cast<const f4*>(out + 4 * l);
-            *reinterpret_cast<f4*>(dst + N) = *reinterpret_cast<const f4*>(out + N + 4 * l);
+            *reinterpret_cast<f4*>(dst) = f4{out[4 * l], out[4 * l + 1], out[4 * l + 2], out[4 * l + 3]};
+            *reinterpret_cast<f4*>(dst + N) = f4{out[N + 4 * l], out[N + 4 * l + 1], out[N + 4 * l + 2], out[N + 4 * l + 3]};
         }
         wave_sync();
     }
