@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
             }
             group16_sort64(uq, l);
         }
-        float tp[4];
+        float tp[4], bin_lo[4], bin_hi[4];
         int guess[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -424,6 +424,7 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
             const float frac = __fsub_rn(u, cb) / den;
             tp[e] = __fadd_rn(bb, __fmul_rn(frac, __fsub_rn(ba, bb)));
             guess[e] = idx;
+            bin_lo[e] = bb; bin_hi[e] = ba;
         }
         // -- the next rays' inputs take over; the ones after them are requested ---------------
         const f4 t_mine = t_cur;
@@ -444,20 +445,19 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
         if (!unsorted) {
             // fine sample j goes to j + #{i : tc[i] <= tp[j]} (a rank next to its bin index), coarse
             // sample i to i + #{j : rank_j <= i} (a histogram of the ranks and a running sum)
-            // The rank lies next to the bin index (the sample was interpolated between the mid points
-            // around tc[idx]): three neighbours settle it without a loop unless values tie or round
-            // across a neighbour, which the loops then finish.
+            // The sample was interpolated between the mid points around tc[idx]: tc[idx - 1] <= mid point
+            // below <= sample and, unless the sum rounded up to it, sample < mid point above <= tc[idx + 1]
+            // (a mid point never leaves the interval of its two ascending neighbours).  One coarse value
+            // then settles the rank; ties, roundings and the bins at the ends go to the loops.
             int rank[4];
             bool settled = true;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v = tp[e];
-                const int r0 = min(guess[e], N - 1);
-                const float lo = tc[max(r0 - 1, 0)], mid = tc[r0], hi = tc[min(r0 + 1, N - 1)];
-                int r = r0 + (mid <= v ? 1 : 0);                          // #{i <= r0 : tc[i] <= v} if tc[r0 - 1] <= v
-                const bool ok = (r0 == 0 || lo <= v) && (mid > v || r0 + 1 >= N || hi > v);
-                settled &= ok;
-                rank[e] = r;
+                const int r0 = guess[e];                                  // 0 .. 63
+                const float mid = tc[r0];
+                rank[e] = r0 + (mid <= v ? 1 : 0);
+                settled &= r0 >= 1 && bin_lo[e] <= v && (mid > v || bin_hi[e] > v || r0 == N - 1);
             }
             if (__builtin_expect(!settled, 0)) {
 #pragma unroll
