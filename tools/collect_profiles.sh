@@ -15,6 +15,8 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tra
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/train_fetch -o f -- python3 bench.py --mode train --steps 5 --warmup 2 > /dev/null 2> $O/train_fetch.err || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/train_write -o w -- python3 bench.py --mode train --steps 5 --warmup 2 > /dev/null 2> $O/train_write.err || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/hbm -o k -- python3 tools/bench_kernels.py > $O/hbm_kernels_under_rocprof.jsonl 2> $O/hbm.err || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sq1 -o a -- python3 tools/bench_kernels.py --iters 2 > /dev/null 2> $O/sq1.err || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/sq2 -o b -- python3 tools/bench_kernels.py --iters 2 > /dev/null 2> $O/sq2.err || exit 1
 timeout -k 10 200 python3 bench.py > $O/bench_full.json 2> $O/bench_full.err || exit 1
 timeout -k 10 120 python3 tools/bench_kernels.py > $O/hbm_kernels.jsonl 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bench_configs.py > $O/other_configs.jsonl 2> $O/other_configs.err || exit 1
