@@ -345,6 +345,9 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
     const bool x_positional = a.ex_kind == NERFX_ENC_POSITIONAL, d_positional = a.ed_kind == NERFX_ENC_POSITIONAL;
     // coordinates as the pair tables want them, in revolutions: v / 2 pi (positional), 2 pi v / 2 pi (Fourier)
     const float x_scale = x_positional ? P::ANGLE_UNIT : 1.0f, d_scale = d_positional ? P::ANGLE_UNIT : 1.0f;
+    // samples of a ray are consecutive points (ray.py:132): with a whole number of 32-sample blocks per
+    // ray, the block of a wave never spans two rays
+    const bool one_ray = a.t != nullptr && a.n_samples % 32 == 0;
 
     // A block's inputs (sample position along the ray, origin, direction) are requested one block
     // ahead, right after the previous block's have been unpacked: their HBM round trip then runs
@@ -449,11 +452,33 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
             ++li;
             // ---- rgb.0 on [phi_d | features] (model.py:53, :76): A -> first half of B ------
             st.mark(ST_EPILOGUE);
+            if (one_ray) {
+                // The 32 samples of this wave's block lie on ONE ray, so all of them have the same phi_d:
+                // its 32 pair-slots are evaluated once, one per lane (lanes 32..63 repeat 0..31), with
+                // the operations of encode_unit16, and every lane picks the 16 bytes of its lane
+                // group's slots up from the wave's stash (phi_x in it is dead after the skip layer;
+                // LDS is in order per wave).
+                const int pair = lane & 31;
+                const float sx = __fmul_rn(d_scale, dx[0]), sy = __fmul_rn(d_scale, dy[0]), sz = __fmul_rn(d_scale, dz[0]);
+                const f32x4 c = NERFX_LDS_VEC(f32x4, cst + a.tabd_off + 4 * pair);
+                float v0, v1;
+                P::sincos_pair(fmaf(sz, c[2], fmaf(sy, c[1], __fmul_rn(sx, c[0]))), v0, v1);
+                if (d_positional && pair == 0) { v0 = dx[0]; v1 = dy[0]; }
+                if (d_positional && pair == 1) { v0 = dz[0]; v1 = 0.0f; }
+                using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+                const bf16x2 packed = {(__bf16)v0, (__bf16)v1};
+                const lds_bytes_t wave_stash = stash_base + wave * M16_STASH_BYTES_PER_WAVE;
+                *reinterpret_cast<__attribute__((address_space(3))) bf16x2*>(wave_stash + 4 * pair) = packed;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const float sx = __fmul_rn(d_scale, dx[s]), sy = __fmul_rn(d_scale, dy[s]), sz = __fmul_rn(d_scale, dz[s]);
+                for (int u = 0; u < M16_ENC_KU; ++u)
+                    encr[u][0] = encr[u][1] = NERFX_LDS_VEC(Frag16, wave_stash + 64 * u + 16 * q);
+            } else {
 #pragma unroll
-                for (int u = 0; u < M16_ENC_KU; ++u) encr[u][s] = encode_unit16(cst + a.tabd_off, d_positional, u, q, sx, sy, sz, dx[s], dy[s], dz[s]);
+                for (int s = 0; s < 2; ++s) {
+                    const float sx = __fmul_rn(d_scale, dx[s]), sy = __fmul_rn(d_scale, dy[s]), sz = __fmul_rn(d_scale, dz[s]);
+#pragma unroll
+                    for (int u = 0; u < M16_ENC_KU; ++u) encr[u][s] = encode_unit16(cst + a.tabd_off, d_positional, u, q, sx, sy, sz, dx[s], dy[s], dz[s]);
+                }
             }
             st.mark(ST_ENCODE);
             linear16<ACT, 8, M16_KU, false, M16_ENC_REGS>(ring, cst + li * BIAS_STRIDE, q, A, B, sigw, dot, st, stash, encr);
