@@ -348,6 +348,16 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
     // samples of a ray are consecutive points (ray.py:132): with a whole number of 32-sample blocks per
     // ray, the block of a wave never spans two rays
     const bool one_ray = a.t != nullptr && a.n_samples % 32 == 0;
+    // An x encoder with 17 .. 20 pair-slots (PE(3, 6): 2 raw + 18) uses, of its second k-unit, only
+    // the first four pair-slots, which are lane group 0's: the groups then evaluate one of them each.
+    const lds_bytes_t wave_stash = stash_base + wave * M16_STASH_BYTES_PER_WAVE;
+    const int x_pairs = (enc_raw_slots(a.ex_kind) + (x_positional ? 6 : 2) * a.ex_n) / 2;
+    const bool x_tail_spread = x_pairs > 16 && x_pairs <= 20;
+    if (x_tail_spread) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            *reinterpret_cast<__attribute__((address_space(3))) Frag16*>(my_stash + (2 + s) * UNIT_BYTES) = __builtin_bit_cast(Frag16, s16x8(0));
+    }
 
     // A block's inputs (sample position along the ray, origin, direction) are requested one block
     // ahead, right after the previous block's have been unpacked: their HBM round trip then runs
@@ -406,10 +416,21 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const float sx = __fmul_rn(x_scale, px[s]), sy = __fmul_rn(x_scale, py[s]), sz = __fmul_rn(x_scale, pz[s]);
-#pragma unroll
-            for (int u = 0; u < M16_ENC_KU; ++u)
-                *reinterpret_cast<__attribute__((address_space(3))) Frag16*>(my_stash + (2 * u + s) * UNIT_BYTES) =
-                    encode_unit16(cst + a.tabx_off, x_positional, u, q, sx, sy, sz, px[s], py[s], pz[s]);
+            *reinterpret_cast<__attribute__((address_space(3))) Frag16*>(my_stash + s * UNIT_BYTES) =
+                encode_unit16(cst + a.tabx_off, x_positional, 0, q, sx, sy, sz, px[s], py[s], pz[s]);
+            if (x_tail_spread) {
+                // the second unit's used pair-slots (16 .. 19, all of lane group 0) one per lane group: the
+                // same operations as encode_unit16, a quarter of them; the other groups' slots stay zero
+                using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+                const f32x4 c = NERFX_LDS_VEC(f32x4, cst + a.tabx_off + 4 * (16 + q));
+                float v0, v1;
+                P::sincos_pair(fmaf(sz, c[2], fmaf(sy, c[1], __fmul_rn(sx, c[0]))), v0, v1);
+                const bf16x2 packed = {(__bf16)v0, (__bf16)v1};
+                *reinterpret_cast<__attribute__((address_space(3))) bf16x2*>(wave_stash + (2 + s) * UNIT_BYTES + col * 16 + 4 * q) = packed;
+            } else {
+                *reinterpret_cast<__attribute__((address_space(3))) Frag16*>(my_stash + (2 + s) * UNIT_BYTES) =
+                    encode_unit16(cst + a.tabx_off, x_positional, 1, q, sx, sy, sz, px[s], py[s], pz[s]);
+            }
         }
         // same wave reads it back: LDS is in order per wave
         const uint32_t stash = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(stash_base + wave * M16_STASH_BYTES_PER_WAVE));
@@ -467,7 +488,6 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
                 if (d_positional && pair == 1) { v0 = dz[0]; v1 = 0.0f; }
                 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
                 const bf16x2 packed = {(__bf16)v0, (__bf16)v1};
-                const lds_bytes_t wave_stash = stash_base + wave * M16_STASH_BYTES_PER_WAVE;
                 *reinterpret_cast<__attribute__((address_space(3))) bf16x2*>(wave_stash + 4 * pair) = packed;
 #pragma unroll
                 for (int u = 0; u < M16_ENC_KU; ++u)
