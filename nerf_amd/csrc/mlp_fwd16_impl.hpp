@@ -230,7 +230,17 @@ __device__ __forceinline__ void linear16(PhasedRing& ring, lds_floats_t bias, in
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) c[t][s][r] = activate<NERFX_PREC_BF16, ACT>(c[t][s][r]);
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (ACT == NERFX_ACT_RELU) {
+                            // fmaxf on a value that comes out of an asm block (the run above) is compiled as two
+                            // v_max_f32, the first only to quiet a signalling NaN: one is enough
+                            float y;
+                            asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(c[t][s][r]));
+                            c[t][s][r] = y;
+                        } else {
+                            c[t][s][r] = activate<NERFX_PREC_BF16, ACT>(c[t][s][r]);
+                        }
+                    }
             }
             if constexpr (SIGMA) {
                 const f32x4 w = NERFX_LDS_VEC(f32x4, sigw + 16 * (grp * 4 + t) + 4 * q);
