@@ -164,6 +164,20 @@ __device__ __forceinline__ Frag16 m16_from_acc(const f32x4& lo, const f32x4& hi)
     return RELU ? P::relu(f) : f;
 }
 
+// Activation of an fp32 accumulator that comes out of a run's asm block.  fmaxf on such a value is
+// compiled as two v_max_f32, the first only to quiet a signalling NaN, which an accumulator never is:
+// LeakyReLU is written out (same values, one instruction fewer); ReLU is an integer max (activate).
+template <int ACT>
+__device__ __forceinline__ float m16_activate(float x) {
+    if constexpr (ACT == NERFX_ACT_LEAKY_RELU) {
+        float y;                                                   // max(x, 0.01f * x)
+        asm("v_mul_f32 %0, 0x3c23d70a, %1\n\tv_max_f32 %0, %1, %0" : "=&v"(y) : "v"(x));
+        return y;
+    } else {
+        return activate<NERFX_PREC_BF16, ACT>(x);
+    }
+}
+
 enum { M16_ENC_NONE = 0, M16_ENC_STASH = 1, M16_ENC_REGS = 2 };
 
 // One Linear layer of NT 16-row output tiles on [encoder k-units | CK chained k-units].
@@ -230,17 +244,7 @@ __device__ __forceinline__ void linear16(PhasedRing& ring, lds_floats_t bias, in
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if constexpr (ACT == NERFX_ACT_RELU) {
-                            // fmaxf on a value that comes out of an asm block (the run above) is compiled as two
-                            // v_max_f32, the first only to quiet a signalling NaN: one is enough
-                            float y;
-                            asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(c[t][s][r]));
-                            c[t][s][r] = y;
-                        } else {
-                            c[t][s][r] = activate<NERFX_PREC_BF16, ACT>(c[t][s][r]);
-                        }
-                    }
+                    for (int r = 0; r < 4; ++r) c[t][s][r] = m16_activate<ACT>(c[t][s][r]);
             }
             if constexpr (SIGMA) {
                 const f32x4 w = NERFX_LDS_VEC(f32x4, sigw + 16 * (grp * 4 + t) + 4 * q);
@@ -311,7 +315,7 @@ __device__ __forceinline__ void linear16_first(PhasedRing& ring, lds_floats_t bi
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) c[t][s][r] = activate<NERFX_PREC_BF16, ACT>(c[t][s][r]);
+                for (int r = 0; r < 4; ++r) c[t][s][r] = m16_activate<ACT>(c[t][s][r]);
         }
         if (t & 1) {
 #pragma unroll

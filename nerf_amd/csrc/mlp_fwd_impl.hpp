@@ -482,7 +482,11 @@ struct Encoding {
 
 template <int PREC, int ACT>
 __device__ __forceinline__ float activate(float x) {
-    if (ACT == NERFX_ACT_RELU) return fmaxf(x, 0.0f);
+    // max(x, 0) on the bits, as signed integers: negative floats (and -0) are negative integers.
+    // fmaxf costs a second v_max_f32 wherever the compiler cannot prove its input is no signalling
+    // NaN (every value that comes out of an asm block); a NaN with a clear sign bit stays a NaN here,
+    // as it does in the reference (model.py:68-74, torch's relu)
+    if (ACT == NERFX_ACT_RELU) return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0));
     if (ACT == NERFX_ACT_LEAKY_RELU) return fmaxf(x, 0.01f * x);       // slope < 1: the larger of the two lines
     if (ACT == NERFX_ACT_SILU) return Prec<PREC>::silu(x);
     return x;                                                // ACT < 0: plain Linear
