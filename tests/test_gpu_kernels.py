@@ -678,6 +678,33 @@ def test_bf16_kernels_agree_with_each_other(ops, name):
     assert torch.equal(part, out[1][0][256 * 700:256 * 900 + 13])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_samples", [128, 96, 48])
+def test_bf16_rays_form_equals_points_form(ops, n_samples):
+    """The ray form of the bf16 inference kernel (positions o + t d formed in the kernel; with a whole
+    number of 32-sample blocks per ray, phi_d evaluated once per block and shared by its lanes) against
+    the point form (every sample brings its own position and direction, phi_d per sample): the same
+    arithmetic on the same values, so the same bits.  128 and 96 samples per ray take the shared path,
+    48 does not."""
+    from nerf_amd import _lib
+    meta, g = load_golden("g3_mlp_base")
+    model = product_model(meta, g)
+    h = ops.handle_for(model)
+    gen = torch.Generator().manual_seed(5)
+    B = 1500
+    # origins, directions and depths on coarse binary grids: t * d and o + t * d are then exact, so the
+    # positions are the same numbers whether a kernel rounds the product before the sum or fuses the two
+    ro = (torch.randint(-64, 65, (B, 3), generator=gen).float() / 64).cuda()
+    rd = (torch.randint(-64, 65, (B, 3), generator=gen).float() / 64).cuda()
+    t = (2.0 + torch.randint(0, 128, (B, n_samples), generator=gen).float() / 32).cuda()
+    s_r, c_r = ops.mlp_rays(h, ro, rd, t, prec=_lib.PREC_BF16)
+    x = ro[:, None, :] + rd[:, None, :] * t[:, :, None]              # ray.py:132
+    d = rd[:, None, :].expand(B, n_samples, 3).contiguous()
+    s_p, c_p = ops.mlp_points(h, x.reshape(-1, 3), d.reshape(-1, 3), prec=_lib.PREC_BF16)
+    assert torch.equal(s_r.reshape(-1), s_p), "sigma differs between the ray form and the point form"
+    assert torch.equal(c_r.reshape(-1, 3), c_p), "rgb differs between the ray form and the point form"
+
+
 WIDE_ENCODER_MODELS = {
     # (phi_x, phi_d, width, depth, activation): which encoder is wider than the register cache of 64 slots
     "x wide, d narrow": (("ff", 40, 4.0), ("ff", 8, 2.0), 256, 4, "ReLU"),
