@@ -44,6 +44,9 @@ __host__ __device__ inline int enc_pairs(int kind, int n) {
 }
 
 #ifdef __HIPCC__
+// (__fmul_rn / __fadd_rn / __fsub_rn below and in the kernels are HIP's plain operators: they name the
+// rounding of one operation, but hipcc still fuses a product with the sum it feeds into one FMA, so
+// o + t * d and the interpolations round once -- at most one ulp from the twice-rounded value.)
 // Angle of sin/cos pair p.  Positional: freq[p / 3] * v[p % 3], one rounding,
 // as `freq * v` in features.py:34.  Fourier: (2 pi v) . b[p] (features.py:51).
 template <class TablePtr>   // global or LDS pointer to floats
