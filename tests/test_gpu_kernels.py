@@ -705,6 +705,32 @@ def test_bf16_rays_form_equals_points_form(ops, n_samples):
     assert torch.equal(c_r.reshape(-1, 3), c_p), "rgb differs between the ray form and the point form"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_x", [5, 6, 7])
+def test_bf16_kernels_agree_for_encoder_tails(ops, n_x):
+    """PE(3, 5) and PE(3, 6) use one and four pair-slots of the x encoder's second k-unit, which the
+    16x16x32 kernel then evaluates one per lane group; PE(3, 7) uses seven and takes the plain path.
+    Against the 32x32x16 kernel on the same bf16 operands (summation order differs, nothing else)."""
+    from nerf_amd import _lib
+    from nerf_amd.core import NeRF, PositionalEncoding
+    torch.manual_seed(100 + n_x)
+    model = NeRF(PositionalEncoding(3, n_x), PositionalEncoding(3, 4), 256, 4).cuda()
+    h = ops.handle_for(model)
+    gen = torch.Generator().manual_seed(23)
+    M = 256 * 300 + 19
+    x = ((torch.rand(M, 3, generator=gen) * 2 - 1) * 3).cuda()
+    d = (torch.rand(M, 3, generator=gen) * 2 - 1).cuda()
+    out = {}
+    try:
+        for m16 in (1, 0):
+            _lib.lib.nerfx_debug_set_m16(m16)
+            out[m16] = ops.mlp_points(h, x, d, prec=_lib.PREC_BF16)
+    finally:
+        _lib.lib.nerfx_debug_set_m16(1)
+    assert_close(out[1][0].cpu(), out[0][0].cpu(), rtol=2e-3, atol=2e-4, what=f"sigma, PE(3,{n_x})")
+    assert_close(out[1][1].cpu(), out[0][1].cpu(), rtol=0, atol=5e-4, what=f"rgb, PE(3,{n_x})")
+
+
 WIDE_ENCODER_MODELS = {
     # (phi_x, phi_d, width, depth, activation): which encoder is wider than the register cache of 64 slots
     "x wide, d narrow": (("ff", 40, 4.0), ("ff", 8, 2.0), 256, 4, "ReLU"),
