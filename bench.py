@@ -91,42 +91,118 @@ def cpu_baseline(model):
                       f"coarse colour head executed as the reference does, best of 3, {best:.2f} s"}
 
 
-def run_roofline(step, prec, steps):
-    """The same step through the staged path (identical kernel sequence, one C call and one event
-    pair per kernel): per-kernel durations, and the fused MLP's achieved FLOP/s."""
+def staged_pass(step, steps):
+    """`steps` steps through the staged path (the kernel sequence of nerfx_render_fwd, one C call and
+    one HIP event pair per kernel, on the launch stream), after one staged step that is thrown away:
+    the first staged step allocates its per-stage tensors, and an allocation between an event pair
+    would be counted as kernel time.  -> {(stage, samples, colour): [ms per launch, ...]}, rays per launch."""
     import nerf_amd.ops as ops
     import torch
-    step()
-    torch.cuda.synchronize()
     ops.PROFILE = []
     try:
+        step()
+        torch.cuda.synchronize()
+        ops.PROFILE = log = []
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
-        log = ops.PROFILE
     finally:
         ops.PROFILE = None
-    stage_ms, mlp_flop, mlp_launches = {}, 0.0, 0
+    per_class = {}
     for stage, b, n, colour, a, z in log:
-        stage_ms[stage] = stage_ms.get(stage, 0.0) + a.elapsed_time(z)
+        per_class.setdefault((stage, b, n, colour), []).append(a.elapsed_time(z))
+    return per_class
+
+
+def median(xs):
+    xs = sorted(xs)
+    return 0.5 * (xs[(len(xs) - 1) // 2] + xs[len(xs) // 2])
+
+
+def roofline_from(per_class, steps, prec, ms_per_step):
+    """The fused MLP's achieved FLOP/s from a staged pass: every launch class (coarse density-only /
+    fine with colours, full and ragged last batch) enters with the MEDIAN of its launch times, so one
+    slow launch cannot move the record.  `stage_ms` = median-based kernel time per step and stage."""
+    stage_ms, mlp_flop, mlp_ms, mlp_launches, classes = {}, 0.0, 0.0, 0, []
+    for (stage, b, n, colour), ms in sorted(per_class.items()):
+        per_step = len(ms) / steps
+        stage_ms[stage] = stage_ms.get(stage, 0.0) + median(ms) * per_step
         if stage == "mlp":
-            mlp_flop += b * n * (FLOP_FULL if colour else FLOP_DENSITY)
-            mlp_launches += 1
-    achieved = mlp_flop / (stage_ms["mlp"] * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "mlp_fwd16_kernel" if prec == "bf16" else "mlp_fwd_kernel", "achieved": achieved, "peak": PEAK_TFLOPS[prec],
-            "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[prec], "traffic": None, "launches": mlp_launches,
-            "avg_launch_ms": stage_ms["mlp"] / mlp_launches, "flop_per_launch": mlp_flop / mlp_launches,
-            "measured": f"HIP events around every kernel of {steps} staged steps after the timed region"}
-    return roof, {k: v / steps for k, v in stage_ms.items()}
+            flop = b * n * (FLOP_FULL if colour else FLOP_DENSITY)
+            mlp_flop += flop * per_step
+            mlp_ms += median(ms) * per_step
+            mlp_launches += per_step
+            classes.append({"rays": b, "samples": n, "colour_head": bool(colour), "launches_per_step": per_step,
+                            "ms": {"min": min(ms), "median": median(ms), "max": max(ms)},
+                            "tflops": flop / (median(ms) * 1e-3) / 1e12,
+                            "frac": flop / (median(ms) * 1e-3) / 1e12 / PEAK_TFLOPS[prec]})
+    achieved = mlp_flop / (mlp_ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": "mlp_fwd16_kernel" if prec == "bf16" else "mlp_fwd_kernel",
+            "achieved": achieved, "peak": PEAK_TFLOPS[prec], "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[prec],
+            "launches_per_step": mlp_launches, "avg_launch_ms": mlp_ms / mlp_launches,
+            "flop_per_launch": mlp_flop / mlp_launches, "kernel_ms_per_step": mlp_ms,
+            "all_stages_ms_per_step": sum(stage_ms.values()),
+            "consistent_with_step": sum(stage_ms.values()) <= 1.05 * ms_per_step,
+            "classes": classes}
+    return roof, stage_ms
+
+
+def run_roofline(step, prec, steps, ms_per_step, flop_per_step):
+    """Staged pass -> roofline record.  The kernels of a step cannot take longer than the step: a pass
+    whose summed kernel time exceeds the timed step by more than 5 % is measured again (at most twice)
+    and the record says how often and whether the last pass agreed.  `frac_from_step` is the bound that
+    holds whatever the staged pass saw: all algorithmic FLOP of a step over the timed step."""
+    tries = 0
+    while True:
+        roof, stage_ms = roofline_from(staged_pass(step, steps), steps, prec, ms_per_step)
+        if roof["consistent_with_step"] or tries == 2:
+            break
+        tries += 1
+    roof["remeasured"] = tries
+    roof["frac_from_step"] = flop_per_step / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[prec]
+    roof["measured"] = (f"HIP events on the launch stream around every kernel of {steps} staged steps (one more staged "
+                        "step first, discarded), median per launch class")
+    return roof, stage_ms
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed counter passes of this same
+    command (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in runs of their own, fetch side corrected for
+    gfx950 as tools/pmc_summary.py states); None when the file is not in the tree."""
+    for name in ("r3_bench_bf16_pmc_hbm.json", "r2_bench_bf16_pmc_hbm.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            for k, v in json.load(open(path))["kernels"].items():
+                if kernel_prefix in k:
+                    return ((v["fetch_corrected_KB"] + v["WRITE_SIZE_KB"]) * 1024.0,
+                            f"profiles/{name}: {k}, fetch_corrected_KB + WRITE_SIZE_KB per launch (counter passes of "
+                            "an earlier run of this command, not of this run)")
+    return None, "no counter summary in profiles/"
 
 
 def time_region(fn, steps, fence):
+    """Wall clock over `steps` calls between two fences, and a HIP event after every call (recorded,
+    never waited for inside the region): -> seconds, [ms of each step on the device]."""
+    import torch
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if torch.cuda.is_available() else None
     fence()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if marks:
+        marks[0].record()
+    for i in range(steps):
         fn()
+        if marks:
+            marks[i + 1].record()
     fence()
-    return time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    series = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)] if marks else []
+    return dt, series
+
+
+def spread(series):
+    """min / avg / max like the reference's bench table (bench.py:99-109), plus the series itself."""
+    return {"min": min(series), "avg": sum(series) / len(series), "max": max(series), "median": median(series),
+            "series": [round(x, 3) for x in series]}
 
 
 def train_leg(args, model, bvr, dev, rank, world, dist, prec, steps, warmup):
@@ -168,7 +244,7 @@ def train_leg(args, model, bvr, dev, rank, world, dist, prec, steps, warmup):
 
     for _ in range(warmup):
         step()
-    dt = time_region(step, steps, fence)
+    dt, series = time_region(step, steps, fence)
     loss = log[warmup + steps - 1].tolist()[0]
     t_max = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -177,7 +253,7 @@ def train_leg(args, model, bvr, dev, rank, world, dist, prec, steps, warmup):
     rate = world * B * steps / dt
     achieved = rate / world * FLOP_TRAIN_PER_RAY / 1e12
     return {"value": rate, "unit": "rays/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
-            "dtype": prec, "rays_per_step_per_gpu": B, "optimizer": args.optim,
+            "dtype": prec, "rays_per_step_per_gpu": B, "optimizer": args.optim, "step_ms": spread(series),
             "roofline": {"bound": "mfma", "kernel": "whole step", "achieved": achieved, "peak": PEAK_TFLOPS[prec],
                          "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[prec]},
             "final_loss": loss}
@@ -303,26 +379,38 @@ def run_rank(args):
         ops.set_precision(args.prec)
         for _ in range(args.warmup):
             step()
-        dt = reduce_max(time_region(step, args.steps, fence))
+        flop_step = n_rays * (NC * FLOP_DENSITY + (NC + NF) * FLOP_FULL)
+        before = None
+        if rank == 0 and not args.no_roofline:                # the staged pass once before the timed region ...
+            before, _ = roofline_from(staged_pass(render_step, 3), 3, args.prec, float("inf"))
+        dt, series = time_region(step, args.steps, fence)
+        dt = reduce_max(dt)
+        ms_step = dt / args.steps * 1e3
+        roof = stage_ms = None
+        if rank == 0 and not args.no_roofline:                # ... and right behind it, for the record
+            roof, stage_ms = run_roofline(render_step, args.prec, 5, ms_step, flop_step)
+            roof["traffic"], roof["traffic_source"] = pmc_traffic("mlp_fwd16_kernel<0, 2, 2>" if args.prec == "bf16" else "mlp_fwd_kernel")
+            roof["before_timed_region"] = {k: before[k] for k in ("frac", "avg_launch_ms", "kernel_ms_per_step")}
         for _ in range(max(1, min(args.warmup, 2))):
             sharded_step()
         k_sh = max(3, min(args.steps, 10))
-        dt_sh = reduce_max(time_region(sharded_step, k_sh, fence))
+        dt_sh, series_sh = time_region(sharded_step, k_sh, fence)
+        dt_sh = reduce_max(dt_sh)
         if rank == 0:
-            roof, stage_ms = run_roofline(render_step, args.prec, 2)
             result = {
                 "metric": "rays/sec (coarse64+fine64)", "value": world * n_rays * args.steps / dt, "unit": "rays/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec,
                 "data": "synthetic",
                 "config": {"workload": f"{args.size}x{args.size} frame per GPU, {WORKLOAD}, perturb off, "
                                        f"{args.batch} rays per render_volume call (nerfx_render_fwd)",
                            "rays_per_step_per_gpu": n_rays, "parallelism": f"frame-sharded x{world}"},
+                "step_ms": spread(series),
                 "roofline": roof, "stage_ms_per_step": stage_ms,
                 "ray_sharded_frame": {
                     "metric": f"ms per {args.size}x{args.size} frame", "ms_per_frame": dt_sh / k_sh * 1e3,
                     "rays_per_s": n_rays * k_sh / dt_sh, "n_gpus": world, "steps": k_sh, "scaling": "strong",
-                    "rays_per_gpu": -(-n_rays // world),
+                    "rays_per_gpu": -(-n_rays // world), "step_ms": spread(series_sh),
                     "includes": "render of ceil(n/N) rays per rank, 16 B/ray gather to rank 0, frame epilogue on rank 0"},
             }
         if world > 1:
@@ -330,10 +418,13 @@ def run_rank(args):
         if world == 1 and not args.no_fp32 and args.prec != "fp32":
             ops.set_precision("fp32")
             render_step()
-            dt32 = time_region(render_step, 3, fence)
-            roof32, _ = run_roofline(render_step, "fp32", 1)
+            dt32, series32 = time_region(render_step, 3, fence)
+            roof32 = None
+            if not args.no_roofline:
+                roof32, _ = run_roofline(render_step, "fp32", 2, dt32 / 3 * 1e3, flop_step)
+                roof32.pop("classes")
             result["fp32"] = {"value": n_rays * 3 / dt32, "unit": "rays/s", "ms_per_step": dt32 / 3 * 1e3, "steps": 3,
-                              "warmup": 1, "dtype": "fp32", "roofline": roof32}
+                              "warmup": 1, "dtype": "fp32", "step_ms": spread(series32), "roofline": roof32}
         ops.set_precision(args.prec)
 
     if not args.no_train:
@@ -361,6 +452,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 sub-record")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-record")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the staged passes (per-kernel events)")
     ap.add_argument("--optim", choices=("fused", "torch"), default="fused", help="Adam implementation of the training leg")
     ap.add_argument("--mode", choices=("render", "train"), default="render",
                     help="render: the headline metric; train: 4,096-ray optimisation steps as the primary record")
