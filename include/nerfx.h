@@ -249,7 +249,9 @@ int nerfx_render_bwd(const nerfx_model_t* last, int precision, const float* rd, 
  * nothing, and rejects (NERFX_E_ARG) more rays than nerfx_render_static_max_rays(nc, nf)
  * (5,957 for 64 + 64 samples).  All calls on one GPU share that array: calls that overlap on the
  * same GPU (two streams, two threads) race; calls on one stream are ordered and safe.  Results
- * are bit-identical to nerfx_render_fwd's. */
+ * are bit-identical to nerfx_render_fwd's.  The FIRST call on a device (with a given model shape and
+ * precision) resolves the array's address and opts its kernels into their LDS sizes, which may load
+ * code objects: make one call per device outside any graph capture before capturing. */
 #define NERFX_STATIC_WORKSPACE_BYTES (16 * 1024 * 1024)
 int64_t nerfx_render_static_max_rays(int nc, int nf);
 int nerfx_render_fwd_static(const nerfx_model_t* coarse, const nerfx_model_t* fine, int precision,

@@ -33,6 +33,31 @@ inline int launch_status(const char* what) {
     return 0;
 }
 
+// ---- dynamic LDS beyond the default limit ---------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a setting of one kernel ON ONE DEVICE: a host
+// thread that drives several GPUs must make it on each.  `LdsOptIn` remembers, per device, the largest
+// size a kernel has been opted into (one static instance per kernel instantiation); `ensure` makes the
+// call for the current device when a launch needs more.  Two threads racing here at worst both make
+// the same call.
+struct LdsOptIn {
+    static constexpr int MAX_DEVICES = 64;
+    size_t bytes[MAX_DEVICES] = {};
+    int ensure(const void* kern, size_t lds_bytes) {
+        int dev = 0;
+        NERFX_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= MAX_DEVICES || lds_bytes > __atomic_load_n(&bytes[dev], __ATOMIC_RELAXED)) {
+            NERFX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            if (dev >= 0 && dev < MAX_DEVICES) __atomic_store_n(&bytes[dev], lds_bytes, __ATOMIC_RELAXED);
+        }
+        return 0;
+    }
+};
+#define NERFX_OPT_IN_LDS(kern, lds_bytes)                                            \
+    do {                                                                             \
+        static ::nerfx::LdsOptIn _opt_in;                                            \
+        if (int _rc = _opt_in.ensure((const void*)(kern), (lds_bytes))) return _rc;  \
+    } while (0)
+
 // ---- encoders ---------------------------------------------------------------
 // Output width of an encoder: 3 + 6 L (features.py:97) or 2 F (features.py:133).
 __host__ __device__ inline int enc_width(int kind, int n) {

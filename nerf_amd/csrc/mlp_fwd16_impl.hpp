@@ -571,11 +571,7 @@ static int launch_cfg16(const MlpArgs& a, hipStream_t stream) {
                              (size_t)RG::WAVES * M16_STASH_BYTES_PER_WAVE;
     NERFX_REQUIRE(lds_bytes <= 160 * 1024, "model needs %zu bytes of LDS per workgroup", lds_bytes);
     NERFX_REQUIRE(a.n_pieces * PIECE_UNITS >= 2u * M16_RING_UNITS, "stream shorter than two ring lengths");
-    static thread_local size_t configured = 0;
-    if (lds_bytes > configured) {
-        NERFX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        configured = lds_bytes;
-    }
+    NERFX_OPT_IN_LDS(kern, lds_bytes);
     int dev = 0, cus = 256;
     NERFX_HIP(hipGetDevice(&dev));
     NERFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));

@@ -962,11 +962,7 @@ static int launch_cfg(const MlpArgs& a, hipStream_t stream) {
     const size_t lds_bytes = (size_t)a.const_floats * sizeof(float) + (size_t)RG::PIECES * PIECE_UNITS * UNIT_BYTES +
                              (uses_stash<PREC, WT, BIGENC>() ? (size_t)RG::WAVES * STASH_BYTES_PER_WAVE : 0);
     NERFX_REQUIRE(lds_bytes * RG::BLOCKS_PER_CU <= 160 * 1024, "model needs %zu bytes of LDS per workgroup", lds_bytes);
-    static thread_local size_t configured = 0;
-    if (lds_bytes > configured) {
-        NERFX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        configured = lds_bytes;
-    }
+    NERFX_OPT_IN_LDS(kern, lds_bytes);
     int dev = 0, cus = 256;
     NERFX_HIP(hipGetDevice(&dev));
     NERFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));

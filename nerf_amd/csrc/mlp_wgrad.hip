@@ -346,14 +346,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WTask* __restri
 #define WGRAD_ROUNDS 2
 #endif
 static int resident_workgroups() {
-    static thread_local int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = 256;
-        slots = 2 * cus;
+    static int slots[LdsOptIn::MAX_DEVICES] = {};                   // per device: two workgroups per CU
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LdsOptIn::MAX_DEVICES) return 2 * 256;
+    if (!__atomic_load_n(&slots[dev], __ATOMIC_RELAXED)) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        __atomic_store_n(&slots[dev], 2 * cus, __ATOMIC_RELAXED);
     }
-    return slots;
+    return __atomic_load_n(&slots[dev], __ATOMIC_RELAXED);
 }
 static void split_plan(int n_tasks, int n_chunks, int& n_split, int& chunks_per_split) {
     if (n_chunks <= 0 || n_tasks <= 0) { n_split = 0; chunks_per_split = 1; return; }
@@ -394,11 +394,7 @@ static int launch_wgrad_prec(const nerfx_model* m, uint64_t m_pad, const void* z
 #define NERFX_WGRAD(ACT_)                                                                                         \
     do {                                                                                                          \
         auto kern = wgrad_kernel<PREC, ACT_>;                                                                     \
-        static thread_local bool configured = false;                                                              \
-        if (!configured) {                                                                                        \
-            NERFX_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            configured = true;                                                                                    \
-        }                                                                                                         \
+        NERFX_OPT_IN_LDS(kern, lds);                                                                              \
         hipLaunchKernelGGL(kern, dim3(n_tasks * n_split), dim3(256), lds, stream, tasks, n_tasks, cps, n_chunks,   \
                            m_pad, (const T*)ztape, (const T*)gtape, partial);                                      \
     } while (0)

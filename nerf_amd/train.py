@@ -109,34 +109,33 @@ def fit(nerf: NeRF, raymarcher: BVR, optim: Optimizer, scheduler: Scheduler, cri
     """Fit `nerf` on a ray dataset (reference train.py:104-177): per epoch a train pass, an
     optional validation pass and the callbacks; a test pass at the end."""
     d = next(nerf.parameters()).device
-    train, val, test = loaders(train_data, val_data, test_data, batch_size, jobs, device=d)
-
+    data = dict(zip(("train", "val", "test"), loaders(train_data, val_data, test_data, batch_size, jobs, device=d)))
     H = History()
-    args = nerf, raymarcher, optim, scheduler, criterion, scaler
+    bar = tqdm(range(epochs), desc="[NeRF] Epoch", disable=not verbose)
 
-    pbar = tqdm(range(epochs), desc="[NeRF] Epoch", disable=not verbose)
-    for epoch in pbar:
-        mse, psnr, lr = step(epoch, *args, train, d, split="train", perturb=perturb, verbose=verbose)
-        H.train.append((np.average(mse), np.average(psnr)))
-        H.lr += lr
-        pbar.set_postfix(mse=np.average(mse), psnr=np.average(psnr))
+    def run(split: str, epoch: int, **options):
+        """One pass over a split -> ((mean loss, mean psnr), learning rates of its steps)."""
+        mse, psnr, lrs = step(epoch, nerf, raymarcher, optim, scheduler, criterion, scaler, data[split], d,
+                              split=split, verbose=verbose, **options)
+        summary = np.average(mse), np.average(psnr)
+        bar.set_postfix(mse=summary[0], psnr=summary[1])
+        return summary, lrs
 
-        if val:
-            mse, psnr, _ = step(epoch, *args, val, d, split="val", verbose=verbose)
-            H.val.append((np.average(mse), np.average(psnr)))
-            pbar.set_postfix(mse=np.average(mse), psnr=np.average(psnr))
-
+    def notify(epoch: int) -> None:
         for callback in callbacks:
             callback(epoch, H)
 
-    if test:
-        mse, psnr, _ = step(epoch, *args, test, d, split="test", verbose=verbose)
-        H.test = np.average(mse), np.average(psnr)
-        pbar.set_postfix(mse=np.average(mse), psnr=np.average(psnr))
-
-        for callback in callbacks:
-            callback(epoch, H)
-
+    last = 0
+    for last in bar:
+        summary, lrs = run("train", last, perturb=perturb)
+        H.train.append(summary)
+        H.lr.extend(lrs)
+        if data["val"]:
+            H.val.append(run("val", last)[0])
+        notify(last)
+    if data["test"]:                                  # after the last epoch, under its number (train.py:169-175)
+        H.test = run("test", last)[0]
+        notify(last)
     return H
 
 

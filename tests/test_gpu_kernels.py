@@ -802,3 +802,51 @@ def test_k4_four_rays_per_wavefront_same_bits(ops):
             same = (a == b) | (a.isnan() & b.isnan())
             assert bool(same.all()), (f"B={B}, uniforms {'given' if uniforms is not None else 'none'}: "
                                       f"{int((~same).sum())} values differ, first at {(~same).nonzero()[0].tolist()}")
+
+
+def _negative_nan():
+    return torch.tensor([-1], dtype=torch.int32).view(torch.float32)[0]      # 0xFFFFFFFF: a NaN with its sign bit set
+
+
+@pytest.mark.parametrize("kernel", ["fp32", "bf16_m16", "bf16_general", "fp32_train", "bf16_train"])
+@pytest.mark.parametrize("where", ["position", "weight", "inf_minus_inf"])
+def test_nan_propagates_through_relu_whatever_its_sign(ops, kernel, where):
+    """torch's relu keeps every NaN (reference model.py:68-74), also one whose sign bit is set (what
+    x86 produces for inf - inf, so a model that diverged on a CPU holds them).  A NaN that enters a
+    sample's hidden layers -- through its position, through a weight, or made inside a layer as
+    inf - inf -- must reach that sample's sigma and rgb as NaN, in every MLP kernel."""
+    from nerf_amd import _lib
+    meta, g = load_golden("g3_mlp_base")
+    model = product_model(meta, g)
+    gen = torch.Generator().manual_seed(31)
+    M = 600
+    x, d = (torch.rand(M, 3, generator=gen) * 2 - 1), (torch.rand(M, 3, generator=gen) * 2 - 1)
+    hit = torch.zeros(M, dtype=torch.bool)
+    with torch.no_grad():
+        if where == "position":
+            x[[5, 300, 599], 1] = _negative_nan()
+            hit[[5, 300, 599]] = True
+        elif where == "weight":
+            dict(model.named_parameters())["fc_1.1.0.weight"][7, 9] = _negative_nan()
+            hit[:] = True
+        else:   # two hidden units at +inf (ReLU keeps them), the next layer subtracts one from the other
+            p = dict(model.named_parameters())
+            p["fc_1.0.0.bias"][3] = float("inf")
+            p["fc_1.0.0.bias"][4] = float("inf")
+            p["fc_1.1.0.weight"][11, 3] = 1.0
+            p["fc_1.1.0.weight"][11, 4] = -1.0
+            hit[:] = True
+    train = kernel.endswith("_train")
+    ops.set_precision("fp32" if kernel.startswith("fp32") else "bf16")
+    try:
+        _lib.lib.nerfx_debug_set_m16(0 if kernel == "bf16_general" else 1)
+        with torch.set_grad_enabled(train):
+            sigma, rgb = model(x.cuda(), d.cuda())
+        assert sigma.requires_grad == train
+    finally:
+        _lib.lib.nerfx_debug_set_m16(1)
+        ops.set_precision(None)
+    sigma, rgb = sigma.detach().cpu(), rgb.detach().cpu()
+    assert bool(torch.isnan(sigma[hit]).all()), f"{int((~torch.isnan(sigma[hit])).sum())} poisoned samples have a finite sigma"
+    assert bool(torch.isnan(rgb[hit]).all()), f"{int((~torch.isnan(rgb[hit]).all(-1)).sum())} poisoned samples have a finite rgb"
+    assert bool(torch.isfinite(sigma[~hit]).all()) and bool(torch.isfinite(rgb[~hit]).all())
