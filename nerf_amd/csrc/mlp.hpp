@@ -216,6 +216,13 @@ struct nerfx_model {
     void* wtasks_dev[2];               // weight-gradient task tables (mlp_wgrad.hip)
     int n_wtasks[2];
     float* const_dev;                  // const block (same for both precisions)
+    // Two words of NAN_* bits (model.hip): refresh number e records in word e & 1 which outputs a NaN
+    // parameter reaches and zeroes the other word for refresh e + 1.  Every refresh reads every
+    // parameter (each forward stream holds all layers), so the word of the latest refresh describes
+    // the current weights, whichever precision it packed.  nan_flag() is what the kernels are given.
+    uint32_t* nan_flags_dev;
+    uint32_t pack_epoch;
+    const uint32_t* nan_flag() const { return nan_flags_dev + (pack_epoch & 1); }
     int n_tensors;
     int device;
 };

@@ -58,6 +58,7 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
     MlpArgs a{};
     a.stream = (const char*)model->stream_dev[precision];
     a.consts = model->const_dev;
+    a.nan_flag = model->nan_flag();
     a.ro = p0; a.rd = p1; a.t = t; a.sigma = sigma; a.rgb = rgb;
     a.n_points = (uint32_t)n_points;
     a.n_samples = (uint32_t)n_samples;

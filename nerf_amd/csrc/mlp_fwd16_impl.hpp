@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
     const lds_bytes_t my_stash = stash_base + wave * M16_STASH_BYTES_PER_WAVE + lane * 16;
     PhasedRing ring;
     ring.init(a.stream, stash_base + WAVES * M16_STASH_BYTES_PER_WAVE, a.n_pieces * PIECE_UNITS, wave, lane);
-    for (int i = tid; i < a.const_floats; i += 64 * WAVES) cst[i] = a.consts[i];
+    load_const_block<64 * WAVES>(a, cst, tid);
     PhasedRing::landed();                                           // this wave's share of the initial fill
     __syncthreads();
 #ifdef NERFX_DIAG_SOLO                           // timing diagnostic (wrong results): group 0 alone, how long is a run by itself?

@@ -40,6 +40,7 @@ using lds_floats_t = const __attribute__((address_space(3))) float*;  // ring mu
 struct MlpArgs {
     const char* stream;          // packed units
     const float* consts;         // const block (global)
+    const uint32_t* nan_flag;    // which outputs a NaN parameter reaches (nerfx_model::nan_flag), or NULL
     const float* ro;             // ray mode: (B,3); point mode: x (M,3)
     const float* rd;             // ray mode: (B,3); point mode: d (M,3)
     const float* t;              // ray mode: (B,n); point mode: NULL
@@ -59,6 +60,22 @@ struct MlpArgs {
     int tape_ex_tile, tape_ed_tile, tape_z_tile[MAX_LAYERS];   // first tile of each encoder / layer
     int tape_tiles;              // tiles in the tape (checked builds trap on anything beyond)
 };
+
+// The const block into LDS.  When the refresh that packed the weights met a NaN parameter, the bias of
+// every head that parameter reaches in the reference becomes NaN here, and with it that head's output
+// for every sample: the density head's bias and the three biases of the last colour layer.
+template <int THREADS>
+__device__ __forceinline__ void load_const_block(const MlpArgs& a, __attribute__((address_space(3))) float* cst, int tid) {
+    const uint32_t poison = a.nan_flag ? __builtin_nontemporal_load(a.nan_flag) : 0u;
+    const int rgb_bias = (2 * a.hd + 2) * BIAS_STRIDE;
+    const float nan = __builtin_bit_cast(float, 0x7FC00000u);
+    for (int i = tid; i < a.const_floats; i += THREADS) {
+        float v = a.consts[i];
+        if ((poison & 1u) && i == a.sigb_off) v = nan;
+        if ((poison & 2u) && i >= rgb_bias && i < rgb_bias + 3) v = nan;
+        cst[i] = v;
+    }
+}
 
 // ---- optional in-kernel cycle accounting (diagnostic builds only: -DNERFX_STAMPS) -------
 // Bucket b accumulates the s_memtime cycles a wave spends between mark(b') and mark(b).
@@ -824,7 +841,7 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
     const lds_bytes_t my_stash = stash_base + wave * STASH_BYTES_PER_WAVE + lane * 16;
     WeightRing<RG> ring;
     ring.init(a.stream, stash_base + (STASH ? WAVES * STASH_BYTES_PER_WAVE : 0), a.n_pieces, wave, lane);
-    for (int i = tid; i < a.const_floats; i += 64 * WAVES) cst[i] = a.consts[i];
+    load_const_block<64 * WAVES>(a, cst, tid);
     __syncthreads();
 
     const lds_floats_t sigw = cst + a.sigw_off;

@@ -94,9 +94,16 @@ int make_plan(const nerfx_model_desc_t& d, int layout, ModelPlan& p) {
     return 0;
 }
 
+// The kernels' ReLU is an integer maximum on the value's bits, which keeps a NaN only while its sign
+// bit is clear.  NaNs made on the device have it clear; a parameter may hold one with the bit set
+// (x86 writes such a NaN for inf - inf), so every parameter enters the packed copies through this.
+__device__ __forceinline__ float sign_free_nan(float v) { return v != v ? __builtin_bit_cast(float, 0x7FC00000u) : v; }
+
 // One thread per packed 16-byte lane slice of one layer (padding units included).
 template <int PREC>
-__device__ __forceinline__ void pack_layer(const float* __restrict__ W, const LayerPlan& L, void* __restrict__ stream) {
+__device__ __forceinline__ void pack_layer(const float* __restrict__ W, const LayerPlan& L, void* __restrict__ stream,
+                                           uint32_t nan_class, uint32_t* nan_flags) {
+    bool saw_nan = false;
     constexpr int EPL = PREC == NERFX_PREC_FP32 ? 4 : 8;          // elements per lane per unit
     constexpr int ROWS = rows_per_tile(PREC), EB = enc_block(PREC);
     const int group_units = L.enc_seg + L.chain_seg;
@@ -149,6 +156,8 @@ __device__ __forceinline__ void pack_layer(const float* __restrict__ W, const La
             } else {
                 v[e] = (live && row < L.out_dim && col >= 0) ? W[(int64_t)row * L.in_dim + col] : 0.0f;
             }
+            saw_nan |= v[e] != v[e];
+            v[e] = sign_free_nan(v[e]);
         }
         char* dst = (char*)stream + (L.unit0 + unit) * UNIT_BYTES + lane * 16;
         if (PREC != NERFX_PREC_FP32) {
@@ -160,25 +169,62 @@ __device__ __forceinline__ void pack_layer(const float* __restrict__ W, const La
             *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[EPL > 3 ? 3 : 0]);
         }
     }
+    if (saw_nan && nan_class) atomicOr(nan_flags, nan_class);
 }
 
-struct PackSources { const float* w[2 * MAX_LAYERS]; };
+// Which outputs a NaN in a parameter reaches in the reference (model.py:68-78): the trunk feeds both
+// heads, `features` / rgb.* only the colour, the density head only the density.
+enum { NAN_SIGMA = 1, NAN_RGB = 2 };
 
-// All layers of both streams of one precision in one launch: blockIdx.y picks the layer plan
-// (forward layers first, then the backward chain's), blockIdx.x strides over its 16-byte slices.
-template <int PREC>
-__global__ __launch_bounds__(256) void pack_streams_kernel(const LayerPlan* __restrict__ plans, int n_fwd, PackSources src,
-                                                           void* __restrict__ fwd, void* __restrict__ bwd) {
-    const LayerPlan L = plans[blockIdx.y];
-    pack_layer<PREC>(src.w[blockIdx.y], L, blockIdx.y < n_fwd ? fwd : bwd);
-}
+// Everything one refresh packs, as ONE launch: blockIdx.y picks a job -- a layer of one stream
+// (forward streams of the layouts in use, then the backward chains'), or one vector of the const
+// block (biases, density-head weights and bias) -- and blockIdx.x strides over a layer's 16-byte
+// slices.  A NaN parameter is recorded in `nan_set` (NAN_* bits): the MLP kernels' ReLU keeps only
+// NaNs whose sign bit is clear and the matrix cores return others, so the kernels are told instead and
+// make the outputs such a parameter reaches NaN, as they are in the reference.  `nan_clear` is the
+// word the NEXT refresh will set bits in; this launch zeroes it (nothing reads it meanwhile).
+struct PackJob { uint8_t layout, plan_index, tensor, nan_class; };
+constexpr int MAX_PACK_JOBS = 6 * MAX_LAYERS;
+constexpr int MAX_VECTORS = MAX_LAYERS + 2;
+struct PackLaunch {
+    const float* tensors[2 + 2 * 16 + 8];
+    const LayerPlan* plans[N_LAYOUTS];
+    void* fwd[N_LAYOUTS];
+    void* bwd[N_LAYOUTS];
+    int n_fwd[N_LAYOUTS];                                  // plans below this index go to fwd, the rest to bwd
+    PackJob job[MAX_PACK_JOBS];
+    int n_jobs, n_vec;
+    uint8_t vec_tensor[MAX_VECTORS], vec_class[MAX_VECTORS];
+    int vec_n[MAX_VECTORS], vec_cap[MAX_VECTORS], vec_off[MAX_VECTORS];
+    float* consts;
+    uint32_t *nan_set, *nan_clear;
+};
 
-struct VectorJobs { const float* src[MAX_LAYERS + 2]; int n[MAX_LAYERS + 2], cap[MAX_LAYERS + 2], off[MAX_LAYERS + 2]; };
-
-// Biases, density-head weights and bias into the const block: blockIdx.y picks the vector.
-__global__ __launch_bounds__(256) void pack_vectors_kernel(VectorJobs jobs, float* __restrict__ consts) {
+__global__ __launch_bounds__(256) void pack_model_kernel(const PackLaunch a) {
     const int j = blockIdx.y;
-    for (int i = threadIdx.x; i < jobs.cap[j]; i += 256) consts[jobs.off[j] + i] = i < jobs.n[j] ? jobs.src[j][i] : 0.0f;
+    if (j < a.n_jobs) {
+        const PackJob job = a.job[j];
+        const LayerPlan L = a.plans[job.layout][job.plan_index];
+        void* dst = job.plan_index < a.n_fwd[job.layout] ? a.fwd[job.layout] : a.bwd[job.layout];
+        const float* W = a.tensors[job.tensor];
+        switch (job.layout) {
+            case NERFX_PREC_FP32: pack_layer<NERFX_PREC_FP32>(W, L, dst, job.nan_class, a.nan_set); break;
+            case NERFX_LAYOUT_M16: pack_layer<NERFX_LAYOUT_M16>(W, L, dst, job.nan_class, a.nan_set); break;
+            default: pack_layer<NERFX_PREC_BF16>(W, L, dst, job.nan_class, a.nan_set); break;   // also the encoder-major stream
+        }
+        return;
+    }
+    if (blockIdx.x) return;
+    const int v = j - a.n_jobs;
+    const float* src = a.tensors[a.vec_tensor[v]];
+    bool saw_nan = false;
+    for (int i = threadIdx.x; i < a.vec_cap[v]; i += 256) {
+        const float x = i < a.vec_n[v] ? src[i] : 0.0f;
+        saw_nan |= x != x;
+        a.consts[a.vec_off[v] + i] = sign_free_nan(x);
+    }
+    if (saw_nan) atomicOr(a.nan_set, (uint32_t)a.vec_class[v]);
+    if (v == 0 && threadIdx.x == 0) *a.nan_clear = 0u;
 }
 
 // Pair-coefficient table of one encoder (see enc_pair_slots): entry k = (cx, cy, cz, 0).
@@ -217,42 +263,40 @@ static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipSt
     const ModelPlan& p0 = m->plan[0];
     const nerfx_model_desc_t& d = p0.desc;
     for (int i = 0; i < m->n_tensors; ++i) NERFX_REQUIRE(tensors[i] != nullptr, "tensor %d is NULL", i);
-    if ((mask >> NERFX_PREC_BF16 & 1) && m->has_m16) {              // the bf16 inference stream of the M16 kernel
-        const ModelPlan& p = m->plan[NERFX_LAYOUT_M16];
-        PackSources src{};
-        for (int li = 0; li < p.n_layers; ++li) src.w[li] = tensors[tensor_index(p, li, false)];
-        hipLaunchKernelGGL(pack_streams_kernel<NERFX_LAYOUT_M16>, dim3(64, p.n_layers), dim3(256), 0, stream,
-                           m->plans_dev[NERFX_LAYOUT_M16], p.n_layers, src, m->stream_dev[NERFX_LAYOUT_M16], nullptr);
-    }
-    if ((mask >> NERFX_PREC_BF16 & 1) && m->has_encmajor) {         // the bf16 inference stream of the wide-encoder kernel
-        const ModelPlan& p = m->plan[NERFX_STREAM_ENCMAJOR];
-        PackSources src{};
-        for (int li = 0; li < p.n_layers; ++li) src.w[li] = tensors[tensor_index(p, li, false)];
-        hipLaunchKernelGGL(pack_streams_kernel<NERFX_PREC_BF16>, dim3(64, p.n_layers), dim3(256), 0, stream,
-                           m->plans_dev[NERFX_STREAM_ENCMAJOR], p.n_layers, src, m->stream_dev[NERFX_STREAM_ENCMAJOR], nullptr);
-    }
-    for (int prec = 0; prec < 2; ++prec) {
-        if (!(mask >> prec & 1)) continue;
-        const ModelPlan& p = m->plan[prec];
-        PackSources src{};
-        for (int li = 0; li < p.n_layers + p.n_bwd; ++li)
-            src.w[li] = tensors[tensor_index(p, li >= p.n_layers ? p.bwd[li - p.n_layers].src_layer : li, false)];
-        const dim3 grid(64, p.n_layers + p.n_bwd);
-        if (prec == NERFX_PREC_BF16)
-            hipLaunchKernelGGL(pack_streams_kernel<NERFX_PREC_BF16>, grid, dim3(256), 0, stream, m->plans_dev[prec], p.n_layers, src,
-                               m->stream_dev[prec], m->stream_bwd_dev[prec]);
-        else
-            hipLaunchKernelGGL(pack_streams_kernel<NERFX_PREC_FP32>, grid, dim3(256), 0, stream, m->plans_dev[prec], p.n_layers, src,
-                               m->stream_dev[prec], m->stream_bwd_dev[prec]);
-    }
-    VectorJobs jobs{};
-    int nj = 0;
-    auto vec = [&](const float* src, int n, int cap, int off) { jobs.src[nj] = src; jobs.n[nj] = n; jobs.cap[nj] = cap; jobs.off[nj] = off; ++nj; };
+    PackLaunch a{};
+    for (int i = 0; i < m->n_tensors; ++i) a.tensors[i] = tensors[i];
+    auto nan_class = [&](int li) { return (uint8_t)(li < 2 * p0.hd ? NAN_SIGMA | NAN_RGB : NAN_RGB); };
+    auto add_stream = [&](int layout, bool with_bwd) {
+        const ModelPlan& p = m->plan[layout];
+        a.plans[layout] = m->plans_dev[layout];
+        a.fwd[layout] = m->stream_dev[layout];
+        a.bwd[layout] = with_bwd ? m->stream_bwd_dev[layout] : nullptr;
+        a.n_fwd[layout] = p.n_layers;
+        for (int li = 0; li < p.n_layers + (with_bwd ? p.n_bwd : 0); ++li) {
+            const bool fwd = li < p.n_layers;
+            const int src_layer = fwd ? li : p.bwd[li - p.n_layers].src_layer;
+            a.job[a.n_jobs++] = PackJob{(uint8_t)layout, (uint8_t)li, (uint8_t)tensor_index(p, src_layer, false),
+                                        fwd ? nan_class(li) : (uint8_t)0};
+        }
+    };
+    const bool bf16 = mask >> NERFX_PREC_BF16 & 1;
+    if (bf16 && m->has_m16) add_stream(NERFX_LAYOUT_M16, false);            // the bf16 inference stream of the M16 kernel
+    if (bf16 && m->has_encmajor) add_stream(NERFX_STREAM_ENCMAJOR, false);  // ... and of the wide-encoder kernel
+    for (int prec = 0; prec < 2; ++prec)
+        if (mask >> prec & 1) add_stream(prec, true);
+    auto vec = [&](int tensor, int n, int cap, int off, int cls) {
+        const int v = a.n_vec++;
+        a.vec_tensor[v] = (uint8_t)tensor; a.vec_class[v] = (uint8_t)cls; a.vec_n[v] = n; a.vec_cap[v] = cap; a.vec_off[v] = off;
+    };
     for (int li = 0; li < p0.n_layers; ++li)
-        vec(tensors[tensor_index(p0, li, true)], p0.layer[li].out_dim, BIAS_STRIDE, li * BIAS_STRIDE);
-    vec(tensors[2 + 4 * p0.hd], d.width, BIAS_STRIDE, p0.sigw_off);
-    vec(tensors[2 + 4 * p0.hd + 1], 1, 4, p0.sigb_off);
-    hipLaunchKernelGGL(pack_vectors_kernel, dim3(1, nj), dim3(256), 0, stream, jobs, m->const_dev);
+        vec(tensor_index(p0, li, true), p0.layer[li].out_dim, BIAS_STRIDE, li * BIAS_STRIDE, nan_class(li));
+    vec(2 + 4 * p0.hd, d.width, BIAS_STRIDE, p0.sigw_off, NAN_SIGMA);
+    vec(2 + 4 * p0.hd + 1, 1, 4, p0.sigb_off, NAN_SIGMA);
+    a.consts = m->const_dev;
+    m->pack_epoch += 1;                                                // see nerfx_model::nan_flags_dev
+    a.nan_set = m->nan_flags_dev + (m->pack_epoch & 1);
+    a.nan_clear = m->nan_flags_dev + ((m->pack_epoch + 1) & 1);
+    hipLaunchKernelGGL(pack_model_kernel, dim3(64, a.n_jobs + a.n_vec), dim3(256), 0, stream, a);
     auto table = [&](const float* src, int kind, int n, int off) {
         const int entries = enc_pair_slots(kind, n);
         hipLaunchKernelGGL(pack_pair_table_kernel, dim3((entries + 255) / 256), dim3(256), 0, stream, src, kind, n, entries,
@@ -294,6 +338,8 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
     for (int prec = 0; prec < 2 && e == hipSuccess; ++prec)
         e = hipMalloc(&m->stream_bwd_dev[prec], (size_t)m->plan[prec].bwd_units * UNIT_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&m->const_dev, (size_t)m->plan[0].const_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->nan_flags_dev, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(m->nan_flags_dev, 0, 2 * sizeof(uint32_t));
     if (e != hipSuccess) {
         nerfx_model_destroy(m);
         return fail(e == hipErrorOutOfMemory ? NERFX_E_NOMEM : NERFX_E_HIP, "model allocation failed: %s", hipGetErrorString(e));
@@ -342,5 +388,6 @@ extern "C" void nerfx_model_destroy(nerfx_model_t* m) {
     for (int prec = 0; prec < N_LAYOUTS; ++prec)
         if (m->plans_dev[prec]) (void)hipFree(m->plans_dev[prec]);
     if (m->const_dev) (void)hipFree(m->const_dev);
+    if (m->nan_flags_dev) (void)hipFree(m->nan_flags_dev);
     delete m;
 }

@@ -809,33 +809,37 @@ def _negative_nan():
 
 
 @pytest.mark.parametrize("kernel", ["fp32", "bf16_m16", "bf16_general", "fp32_train", "bf16_train"])
-@pytest.mark.parametrize("where", ["position", "weight", "inf_minus_inf"])
-def test_nan_propagates_through_relu_whatever_its_sign(ops, kernel, where):
+@pytest.mark.parametrize("where", ["position", "weight", "bias", "colour_weight", "density_head"])
+def test_nan_inputs_and_parameters_poison_the_outputs(ops, kernel, where):
     """torch's relu keeps every NaN (reference model.py:68-74), also one whose sign bit is set (what
-    x86 produces for inf - inf, so a model that diverged on a CPU holds them).  A NaN that enters a
-    sample's hidden layers -- through its position, through a weight, or made inside a layer as
-    inf - inf -- must reach that sample's sigma and rgb as NaN, in every MLP kernel."""
+    x86 writes for inf - inf, so a model that diverged on a CPU holds them); the kernels' integer-max
+    ReLU alone would drop those.  A NaN position poisons its sample; a NaN parameter poisons, for every
+    sample, the outputs it reaches in the reference: both for a trunk weight or bias, only rgb for the
+    colour layers, only sigma for the density head.  In every MLP kernel."""
     from nerf_amd import _lib
     meta, g = load_golden("g3_mlp_base")
     model = product_model(meta, g)
     gen = torch.Generator().manual_seed(31)
     M = 600
     x, d = (torch.rand(M, 3, generator=gen) * 2 - 1), (torch.rand(M, 3, generator=gen) * 2 - 1)
-    hit = torch.zeros(M, dtype=torch.bool)
+    hit_s, hit_c = torch.zeros(M, dtype=torch.bool), torch.zeros(M, dtype=torch.bool)
     with torch.no_grad():
+        p = dict(model.named_parameters())
         if where == "position":
             x[[5, 300, 599], 1] = _negative_nan()
-            hit[[5, 300, 599]] = True
+            hit_s[[5, 300, 599]] = hit_c[[5, 300, 599]] = True
         elif where == "weight":
-            dict(model.named_parameters())["fc_1.1.0.weight"][7, 9] = _negative_nan()
-            hit[:] = True
-        else:   # two hidden units at +inf (ReLU keeps them), the next layer subtracts one from the other
-            p = dict(model.named_parameters())
-            p["fc_1.0.0.bias"][3] = float("inf")
-            p["fc_1.0.0.bias"][4] = float("inf")
-            p["fc_1.1.0.weight"][11, 3] = 1.0
-            p["fc_1.1.0.weight"][11, 4] = -1.0
-            hit[:] = True
+            p["fc_1.1.0.weight"][7, 9] = _negative_nan()
+            hit_s[:] = hit_c[:] = True
+        elif where == "bias":
+            p["fc_2.0.0.bias"][200] = float("nan")
+            hit_s[:] = hit_c[:] = True
+        elif where == "colour_weight":
+            p["rgb.0.weight"][100, 50] = _negative_nan()
+            hit_c[:] = True
+        else:
+            p["sigma.0.weight"][0, 17] = _negative_nan()
+            hit_s[:] = True
     train = kernel.endswith("_train")
     ops.set_precision("fp32" if kernel.startswith("fp32") else "bf16")
     try:
@@ -847,6 +851,14 @@ def test_nan_propagates_through_relu_whatever_its_sign(ops, kernel, where):
         _lib.lib.nerfx_debug_set_m16(1)
         ops.set_precision(None)
     sigma, rgb = sigma.detach().cpu(), rgb.detach().cpu()
-    assert bool(torch.isnan(sigma[hit]).all()), f"{int((~torch.isnan(sigma[hit])).sum())} poisoned samples have a finite sigma"
-    assert bool(torch.isnan(rgb[hit]).all()), f"{int((~torch.isnan(rgb[hit]).all(-1)).sum())} poisoned samples have a finite rgb"
-    assert bool(torch.isfinite(sigma[~hit]).all()) and bool(torch.isfinite(rgb[~hit]).all())
+    assert bool(torch.isnan(sigma[hit_s]).all()), f"{int((~torch.isnan(sigma[hit_s])).sum())} poisoned samples have a finite sigma"
+    assert bool(torch.isnan(rgb[hit_c]).all()), f"{int((~torch.isnan(rgb[hit_c]).all(-1)).sum())} poisoned samples have a finite rgb"
+    assert bool(torch.isfinite(sigma[~hit_s]).all()) and bool(torch.isfinite(rgb[~hit_c]).all())
+    # and the flag goes away with the NaN
+    if where != "position":
+        model.load_state_dict({k: torch.nan_to_num(v, nan=0.01) for k, v in model.state_dict().items()})
+        ops.set_precision("fp32" if kernel.startswith("fp32") else "bf16")
+        with torch.no_grad():
+            sigma, rgb = model(x.cuda(), d.cuda())
+        ops.set_precision(None)
+        assert bool(torch.isfinite(sigma).all()) and bool(torch.isfinite(rgb).all()), "outputs stay poisoned after the NaN is gone"

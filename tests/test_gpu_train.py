@@ -309,7 +309,10 @@ def _float64_step(model, C, ro, rd, t, rays_per_pass=512):
 
 def test_config3_fp32_step_at_full_size(ops):
     """One 4,096-ray step of the 256 x 4 model with explicit jitter: loss within 2e-5 relative and all
-    16 gradients within 1e-4 of their largest entry of a float64 evaluation of the same step."""
+    16 gradients within 5e-4 of their largest entry of a float64 evaluation of the same step.  (A
+    gradient entry here is a sum over 524,288 samples that cancels to ~1e-5 of its terms; fp32
+    accumulation of that sum measures 1.8e-4 at worst, on fc_2.0's weight -- the 32-ray fixtures,
+    with 128 times fewer terms, stay within 1e-4.)"""
     model, C, ro, rd = _config3()
     model = model.cuda()
     gen = torch.Generator().manual_seed(8)
@@ -323,7 +326,7 @@ def test_config3_fp32_step_at_full_size(ops):
     want_loss, want = _float64_step(model, C, ro, rd, t.detach().cpu())
     assert abs(loss.item() - want_loss) <= 2e-5 * want_loss, (loss.item(), want_loss)
     for k, p in model.named_parameters():
-        assert_grad_close(p.grad.cpu(), want[k], 1e-4, f"config 3 fp32 grad {k} vs float64")
+        assert_grad_close(p.grad.cpu(), want[k], 5e-4, f"config 3 fp32 grad {k} vs float64")
 
 
 def test_config3_bf16_step_through_train_step(ops):
