@@ -206,13 +206,16 @@ def spread(series):
 
 
 def train_leg(args, model, bvr, dev, rank, world, dist, prec, steps, warmup):
-    """A step = one optimisation step on 4,096 rays per GPU exactly as nerf_amd.train.step runs it
-    (render train=True, perturb on, fused MSE + PSNR, backward, gradient all-reduce for N > 1,
-    unscale_, Adam, scaler update; losses stay on the device), batches resident in HBM."""
+    """A step = one optimisation step on 4,096 rays per GPU through nerf_amd.train.batch_step, the body
+    of train.step's loop (render train=True with perturb, MSE + PSNR, backward, gradient all-reduce for
+    N > 1, the GradScaler's unscale / inf check / step / update, Adam, scheduler; losses stay on the
+    device), batches resident in HBM."""
     import torch
     import nerf_amd.ops as ops
-    from nerf_amd.distributed import average_gradients, broadcast_parameters, seed_ranks
+    from nerf_amd.core import IndendityScheduler
+    from nerf_amd.distributed import broadcast_parameters, seed_ranks
     from nerf_amd.optim import Adam
+    from nerf_amd.train import batch_step
     B = 4096
     broadcast_parameters(model)
     seed_ranks(1234)                                         # independent perturb draws per rank
@@ -220,22 +223,16 @@ def train_leg(args, model, bvr, dev, rank, world, dist, prec, steps, warmup):
     C, ro, rd = (torch.rand(B, 3, device=dev, generator=g) for _ in range(3))
     eps = 1e-4 if prec == "bf16" else 1e-8
     optim = (torch.optim.Adam if args.optim == "torch" else Adam)(model.parameters(), lr=5e-4, eps=eps)
+    scheduler = IndendityScheduler(optim, 1, 5e-4)
+    criterion = torch.nn.MSELoss()
     scaler = torch.amp.GradScaler("cuda", enabled=prec == "bf16")
     log = torch.zeros((warmup + steps, 2), device=dev)
     done = [0]
     ops.set_precision(prec)
 
-    def step():
-        k = done[0]
-        *_, C_ = bvr.render_volume(model, model, ro, rd, perturb=True, train=True)
-        loss = ops.mse_loss(C_, C, log[k])
-        scaler.scale(loss).backward()
-        average_gradients(model)
-        scaler.unscale_(optim)
-        scaler.step(optim)
-        scaler.update()
-        optim.zero_grad(set_to_none=True)
-        done[0] = k + 1
+    def step():                                              # the body of nerf_amd.train.step's loop
+        batch_step(model, bvr, optim, scheduler, criterion, scaler, C, ro, rd, True, log[done[0]])
+        done[0] += 1
 
     def fence():
         if world > 1:

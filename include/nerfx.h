@@ -158,6 +158,14 @@ int nerfx_mlp_bwd(const nerfx_model_t* model, int precision, int64_t n_points,
                   const float* g_sigma, const float* g_rgb,
                   void* workspace, int64_t workspace_bytes,
                   float* const* grads /* host array */, int n_grads, void* stream);
+/* The same, with the GradScaler's check of train.py:81 (scaler.unscale_ looks for inf / NaN in every
+ * gradient) made where the gradients are written: *found_inf (a device float the caller has zeroed,
+ * e.g. with nerfx_mse_loss_scaled; may be NULL) is set to 1 when any gradient element is not finite. */
+int nerfx_mlp_bwd_checked(const nerfx_model_t* model, int precision, int64_t n_points,
+                          const float* sigma, const float* rgb,
+                          const float* g_sigma, const float* g_rgb,
+                          void* workspace, int64_t workspace_bytes,
+                          float* const* grads /* host array */, int n_grads, float* found_inf, void* stream);
 
 /* ---- K3: alpha compositing ------------------------------------------------
  * Replaces segment_lengths (ray.py:60-66), raymarch_volume + exclusive_cumprod
@@ -241,6 +249,11 @@ int nerfx_render_bwd(const nerfx_model_t* last, int precision, const float* rd, 
                      const float* t, const float* g_rgb_map, const float* g_depth, const float* g_weights,
                      void* workspace, int64_t workspace_bytes, float* const* grads /* host array */, int n_grads,
                      void* stream);
+/* nerfx_render_bwd with the gradient check of nerfx_mlp_bwd_checked. */
+int nerfx_render_bwd_checked(const nerfx_model_t* last, int precision, const float* rd, int64_t n_rays, int nc, int nf,
+                             const float* t, const float* g_rgb_map, const float* g_depth, const float* g_weights,
+                             void* workspace, int64_t workspace_bytes, float* const* grads /* host array */, int n_grads,
+                             float* found_inf, void* stream);
 
 /* The same render for callers that cannot allocate device memory (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The
@@ -297,6 +310,11 @@ int nerfx_gather_rays(const float* C, const float* ro, const float* rd, const in
  * One fixed summation order: bit-reproducible. */
 int nerfx_mse_loss(const float* pred, const float* target, int64_t n_elements, float* loss_psnr,
                    float* grad_seed, void* stream);
+/* The same for a step behind a GradScaler (train.py:77-80): grad_seed = d (*loss_scale x loss) / d pred,
+ * what scaler.scale(loss).backward() seeds the graph with (loss_psnr stay unscaled); *found_inf
+ * (device float, may be NULL) is zeroed for the backward that follows (nerfx_render_bwd_checked). */
+int nerfx_mse_loss_scaled(const float* pred, const float* target, int64_t n_elements, float* loss_psnr,
+                          float* grad_seed, const float* loss_scale, float* found_inf, void* stream);
 /* torch.optim.Adam's update (train.py:246) over flat fp32 arrays of n elements, with the
  * GradScaler's part of train.py:82-85 folded in: gradients are multiplied by *inv_scale when
  * given, and nothing is updated when *found_inf != 0 (device floats, may be NULL).  The update
@@ -306,6 +324,13 @@ int nerfx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float lr, float beta1, float beta2, float eps, float weight_decay,
                     const float* inv_scale, const float* found_inf,
                     const float* step_in, float* step_out, void* stream);
+/* The same taking the loss scale itself (the device float a GradScaler keeps): gradients are
+ * multiplied by 1 / *grad_scale, which is scaler.unscale_ (train.py:81) and scaler.step
+ * (train.py:83) in one pass with the update. */
+int nerfx_adam_step_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                           float lr, float beta1, float beta2, float eps, float weight_decay,
+                           const float* grad_scale, const float* found_inf,
+                           const float* step_in, float* step_out, void* stream);
 
 /* Distillation loss of distill.py:120-130 and its gradient w.r.t. the student's outputs:
  * loss = mean_i [ mean_j (alpha(s_sigma_i, delta_j) - alpha(t_sigma_i, delta_j))^2

@@ -51,6 +51,7 @@ SIGNATURES = {
     "nerfx_mlp_fwd_train_points": (_i, [_p, _i, _p, _p, _l, _p, _p, _p, _l, _p]),
     "nerfx_mlp_fwd_train_rays": (_i, [_p, _i, _p, _p, _p, _l, _i, _p, _p, _p, _l, _p]),
     "nerfx_mlp_bwd": (_i, [_p, _i, _l, _p, _p, _p, _p, _p, _l, C.POINTER(_p), _i, _p]),
+    "nerfx_mlp_bwd_checked": (_i, [_p, _i, _l, _p, _p, _p, _p, _p, _l, C.POINTER(_p), _i, _p, _p]),
     "nerfx_composite_fwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
     "nerfx_composite_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p]),
     "nerfx_segment_lengths": (_i, [_p, _p, _l, _i, _p, _p]),
@@ -64,7 +65,9 @@ SIGNATURES = {
     "nerfx_frame_finish": (_i, [_p, _p, _l, _p, _l, _p, _p, _p, _p, _p]),
     "nerfx_gather_rays": (_i, [_p, _p, _p, _p, _l, _l, _l, _p, _p, _p, _p]),
     "nerfx_mse_loss": (_i, [_p, _p, _l, _p, _p, _p]),
+    "nerfx_mse_loss_scaled": (_i, [_p, _p, _l, _p, _p, _p, _p, _p]),
     "nerfx_adam_step": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
+    "nerfx_adam_step_scaled": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
     "nerfx_voxel_sample": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, C.c_uint64, C.c_uint64, _p, _p, _p, _p]),
     "nerfx_distill_loss": (_i, [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p]),
     "nerfx_debug_set_stamps": (None, [_p]),
@@ -80,6 +83,7 @@ SIGNATURES = {
     "nerfx_render_train_fwd": (_i, [_p, _p, _i, _p, _p, _l, _f, _f, _i, _i, _p, _p, C.POINTER(Rng), _p, _l,
                                     _p, _p, _p, _p, _p]),
     "nerfx_render_bwd": (_i, [_p, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _l, C.POINTER(_p), _i, _p]),
+    "nerfx_render_bwd_checked": (_i, [_p, _i, _p, _l, _i, _i, _p, _p, _p, _p, _p, _l, C.POINTER(_p), _i, _p, _p]),
     "nerfx_render_static_max_rays": (_l, [_i, _i]),
     "nerfx_render_fwd_static": (_i, [_p, _p, _i, _p, _p, _l, _f, _f, _i, _i, _p, _p,
                                      _p, _p, _p, _p, _p]),

@@ -21,7 +21,7 @@ int launch_mlp_bwd_bf16(int activ, int wt, const BwdArgs& a, hipStream_t s);
 int launch_mlp_bwd_fp32(int activ, int wt, const BwdArgs& a, hipStream_t s);
 int64_t wgrad_partial_bytes(const nerfx_model* m, int prec, uint64_t m_pad);
 int launch_wgrad(const nerfx_model* m, int prec, uint64_t m_pad, const void* ztape, const void* gtape, float* partial,
-                 float* const* grads, int n_grads, hipStream_t stream);
+                 float* const* grads, int n_grads, float* found_inf, hipStream_t stream);
 }  // namespace nerfx
 
 using namespace nerfx;
@@ -174,9 +174,10 @@ extern "C" int nerfx_mlp_fwd_train_rays(const nerfx_model_t* model, int precisio
     return train_fwd(model, precision, ro, rd, t, n_rays * n_samples, n_samples, sigma, rgb, workspace, workspace_bytes, stream);
 }
 
-extern "C" int nerfx_mlp_bwd(const nerfx_model_t* model, int precision, int64_t n_points, const float* sigma,
-                             const float* rgb, const float* g_sigma, const float* g_rgb, void* workspace,
-                             int64_t workspace_bytes, float* const* grads, int n_grads, void* stream) {
+extern "C" int nerfx_mlp_bwd_checked(const nerfx_model_t* model, int precision, int64_t n_points, const float* sigma,
+                                     const float* rgb, const float* g_sigma, const float* g_rgb, void* workspace,
+                                     int64_t workspace_bytes, float* const* grads, int n_grads, float* found_inf,
+                                     void* stream) {
     NERFX_REQUIRE(model != nullptr, "model is NULL");
     NERFX_REQUIRE(precision == NERFX_PREC_FP32 || precision == NERFX_PREC_BF16, "unknown precision %d", precision);
     NERFX_REQUIRE(n_points > 0 && n_points < (int64_t)1 << 31, "n_points %lld out of range (0, 2^31)", (long long)n_points);
@@ -201,5 +202,12 @@ extern "C" int nerfx_mlp_bwd(const nerfx_model_t* model, int precision, int64_t 
     a.heads_tile = p.tape_heads_tile; a.n_tiles = p.tape_tiles;
     if (int rc = (precision == NERFX_PREC_BF16 ? launch_mlp_bwd_bf16 : launch_mlp_bwd_fp32)(p.desc.activ, p.wt, a, (hipStream_t)stream))
         return rc;
-    return launch_wgrad(model, precision, w.m_pad, w.ztape, w.gtape, w.partial, grads, n_grads, (hipStream_t)stream);
+    return launch_wgrad(model, precision, w.m_pad, w.ztape, w.gtape, w.partial, grads, n_grads, found_inf, (hipStream_t)stream);
+}
+
+extern "C" int nerfx_mlp_bwd(const nerfx_model_t* model, int precision, int64_t n_points, const float* sigma,
+                             const float* rgb, const float* g_sigma, const float* g_rgb, void* workspace,
+                             int64_t workspace_bytes, float* const* grads, int n_grads, void* stream) {
+    return nerfx_mlp_bwd_checked(model, precision, n_points, sigma, rgb, g_sigma, g_rgb, workspace, workspace_bytes,
+                                 grads, n_grads, nullptr, stream);
 }

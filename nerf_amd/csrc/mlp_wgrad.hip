@@ -306,7 +306,8 @@ __device__ __forceinline__ int tile_position_feature(int p) { return (p & 3) + 8
 
 // Sums the splits of one task element in split order and writes it where it belongs.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WTask* __restrict__ tasks, int n_tasks, int n_split,
-                                                           const float* __restrict__ partial, GradList grads) {
+                                                           const float* __restrict__ partial, GradList grads,
+                                                           float* __restrict__ found_inf) {
     constexpr int PER_TASK = TASK_TILES * 1024;
     const int task = blockIdx.x / (PER_TASK / 256), e = (blockIdx.x % (PER_TASK / 256)) * 256 + threadIdx.x;
     const WTask& tk = tasks[task];
@@ -336,6 +337,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WTask* __restri
     if (!dst) return;
     float sum = 0.0f;
     for (int ks = 0; ks < n_split; ++ks) sum += partial[((size_t)ks * n_tasks + task) * PER_TASK + e];
+    // the GradScaler's check (train.py:81) where the gradient is written: every element passes here once
+    if (found_inf && !(fabsf(sum) <= 3.402823466e38f)) *found_inf = 1.0f;
     if (col < 0) dst[row] = sum;
     else dst[(size_t)row * tk.ld + col] = sum;
 }
@@ -383,7 +386,7 @@ int64_t wgrad_partial_bytes(const nerfx_model* m, int prec, uint64_t m_pad) {
 
 template <int PREC>
 static int launch_wgrad_prec(const nerfx_model* m, uint64_t m_pad, const void* ztape, const void* gtape, float* partial,
-                             const GradList& grads, hipStream_t stream) {
+                             const GradList& grads, float* found_inf, hipStream_t stream) {
     using O = WOperand<PREC>;
     using T = typename O::T;
     const int n_tasks = m->n_wtasks[PREC], n_chunks = (int)(m_pad / O::CHUNK);
@@ -405,16 +408,16 @@ static int launch_wgrad_prec(const nerfx_model* m, uint64_t m_pad, const void* z
     }
 #undef NERFX_WGRAD
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(n_tasks * (TASK_TILES * 1024 / 256)), dim3(256), 0, stream, tasks,
-                       n_tasks, n_split, partial, grads);
+                       n_tasks, n_split, partial, grads, found_inf);
     return launch_status("wgrad kernels");
 }
 
 int launch_wgrad(const nerfx_model* m, int prec, uint64_t m_pad, const void* ztape, const void* gtape, float* partial,
-                 float* const* grads, int n_grads, hipStream_t stream) {
+                 float* const* grads, int n_grads, float* found_inf, hipStream_t stream) {
     GradList g{};
     for (int i = 0; i < n_grads; ++i) g.p[i] = grads[i];
-    return prec == NERFX_PREC_BF16 ? launch_wgrad_prec<NERFX_PREC_BF16>(m, m_pad, ztape, gtape, partial, g, stream)
-                                   : launch_wgrad_prec<NERFX_PREC_FP32>(m, m_pad, ztape, gtape, partial, g, stream);
+    return prec == NERFX_PREC_BF16 ? launch_wgrad_prec<NERFX_PREC_BF16>(m, m_pad, ztape, gtape, partial, g, found_inf, stream)
+                                   : launch_wgrad_prec<NERFX_PREC_FP32>(m, m_pad, ztape, gtape, partial, g, found_inf, stream);
 }
 
 }  // namespace nerfx

@@ -175,9 +175,10 @@ extern "C" int nerfx_render_train_fwd(const nerfx_model_t* coarse, const nerfx_m
                            depth_map, rgb_map, stream);
 }
 
-extern "C" int nerfx_render_bwd(const nerfx_model_t* last, int precision, const float* rd, int64_t n_rays, int nc, int nf,
-                                const float* t, const float* g_rgb_map, const float* g_depth, const float* g_weights,
-                                void* workspace, int64_t workspace_bytes, float* const* grads, int n_grads, void* stream) {
+extern "C" int nerfx_render_bwd_checked(const nerfx_model_t* last, int precision, const float* rd, int64_t n_rays, int nc,
+                                        int nf, const float* t, const float* g_rgb_map, const float* g_depth,
+                                        const float* g_weights, void* workspace, int64_t workspace_bytes,
+                                        float* const* grads, int n_grads, float* found_inf, void* stream) {
     NERFX_REQUIRE(n_rays > 0 && nc >= 1 && nf >= 0, "bad ray / sample counts");
     NERFX_REQUIRE(last && rd && t && grads, "NULL argument");
     const int64_t need = nerfx_render_train_workspace_bytes(last, precision, n_rays, nc, nf);
@@ -189,8 +190,15 @@ extern "C" int nerfx_render_bwd(const nerfx_model_t* last, int precision, const 
     // autograd of renderer.py:50-57, :203, then of model.py:68-78
     if (int rc = nerfx_composite_bwd(s.w.sigma_f, s.w.rgb_f, t, rd, nullptr, n_rays, n, g_rgb_map, g_depth, g_weights,
                                      s.g_sigma, s.g_rgb, stream)) return rc;
-    return nerfx_mlp_bwd(last, precision, n_rays * n, s.w.sigma_f, s.w.rgb_f, s.g_sigma, s.g_rgb, s.tape, s.tape_bytes,
-                         grads, n_grads, stream);
+    return nerfx_mlp_bwd_checked(last, precision, n_rays * n, s.w.sigma_f, s.w.rgb_f, s.g_sigma, s.g_rgb, s.tape,
+                                 s.tape_bytes, grads, n_grads, found_inf, stream);
+}
+
+extern "C" int nerfx_render_bwd(const nerfx_model_t* last, int precision, const float* rd, int64_t n_rays, int nc, int nf,
+                                const float* t, const float* g_rgb_map, const float* g_depth, const float* g_weights,
+                                void* workspace, int64_t workspace_bytes, float* const* grads, int n_grads, void* stream) {
+    return nerfx_render_bwd_checked(last, precision, rd, n_rays, nc, nf, t, g_rgb_map, g_depth, g_weights, workspace,
+                                    workspace_bytes, grads, n_grads, nullptr, stream);
 }
 
 extern "C" int64_t nerfx_render_static_max_rays(int nc, int nf) {

@@ -29,9 +29,13 @@ __global__ __launch_bounds__(256) void gather_rays_kernel(const float* __restric
 constexpr int MSE_THREADS = 1024;
 __global__ __launch_bounds__(MSE_THREADS) void mse_loss_kernel(const float* __restrict__ pred,
                                                                const float* __restrict__ target, int64_t n,
-                                                               float* __restrict__ out2, float* __restrict__ seed) {
+                                                               float* __restrict__ out2, float* __restrict__ seed,
+                                                               const float* __restrict__ loss_scale,
+                                                               float* __restrict__ found_inf) {
     __shared__ float part[MSE_THREADS / 64];
-    const float inv_n = 1.0f / (float)n, two_inv_n = 2.0f / (float)n;
+    // the seed of scaler.scale(loss).backward() (train.py:80): d (scale * loss) / d pred
+    const float inv_n = 1.0f / (float)n, two_inv_n = (loss_scale ? *loss_scale : 1.0f) * (2.0f / (float)n);
+    if (found_inf && threadIdx.x == 0) *found_inf = 0.f;             // the backward that follows raises it
     float acc = 0.f;
     for (int64_t q = threadIdx.x; q < n; q += MSE_THREADS) {
         const float d = pred[q] - target[q];
@@ -60,6 +64,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ para
                                                         float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                                         int64_t n, float lr, float beta1, float beta2, float eps,
                                                         float weight_decay, const float* __restrict__ inv_scale,
+                                                        const float* __restrict__ grad_scale,
                                                         const float* __restrict__ found_inf,
                                                         const float* __restrict__ step_in, float* __restrict__ step_out) {
     const bool skip = found_inf && *found_inf != 0.f;
@@ -69,7 +74,8 @@ __global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ para
     // bias corrections in double like the Python scalars of torch.optim.Adam
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
-    const float unscale = inv_scale ? *inv_scale : 1.0f;
+    // GradScaler.unscale_ multiplies by 1 / scale, the reciprocal taken once (grad_scaler.py)
+    const float unscale = inv_scale ? *inv_scale : (grad_scale ? 1.0f / *grad_scale : 1.0f);
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (int64_t)gridDim.x * 256) {
         float g = grad[q] * unscale;
         const float p = param[q];
@@ -156,27 +162,48 @@ extern "C" int nerfx_gather_rays(const float* C, const float* ro, const float* r
     return launch_status("gather_rays_kernel");
 }
 
-extern "C" int nerfx_mse_loss(const float* pred, const float* target, int64_t n_elements, float* loss_psnr,
-                              float* grad_seed, void* stream) {
+extern "C" int nerfx_mse_loss_scaled(const float* pred, const float* target, int64_t n_elements, float* loss_psnr,
+                                     float* grad_seed, const float* loss_scale, float* found_inf, void* stream) {
     NERFX_REQUIRE(n_elements > 0, "n_elements <= 0");
     NERFX_REQUIRE(pred && target && loss_psnr, "pred / target / loss_psnr is NULL");
     hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(MSE_THREADS), 0, (hipStream_t)stream, pred, target, n_elements,
-                       loss_psnr, grad_seed);
+                       loss_psnr, grad_seed, loss_scale, found_inf);
     return launch_status("mse_loss_kernel");
 }
 
-extern "C" int nerfx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                               float lr, float beta1, float beta2, float eps, float weight_decay,
-                               const float* inv_scale, const float* found_inf, const float* step_in,
-                               float* step_out, void* stream) {
+extern "C" int nerfx_mse_loss(const float* pred, const float* target, int64_t n_elements, float* loss_psnr,
+                              float* grad_seed, void* stream) {
+    return nerfx_mse_loss_scaled(pred, target, n_elements, loss_psnr, grad_seed, nullptr, nullptr, stream);
+}
+
+static int adam_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay,
+                       const float* inv_scale, const float* grad_scale, const float* found_inf, const float* step_in,
+                       float* step_out, void* stream) {
     NERFX_REQUIRE(n >= 0, "n < 0");
     NERFX_REQUIRE(step_in && step_out && step_in != step_out, "step_in / step_out must be two device floats");
     NERFX_REQUIRE(n == 0 || (param && grad && exp_avg && exp_avg_sq), "param / grad / exp_avg / exp_avg_sq is NULL");
     NERFX_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "betas outside [0, 1)");
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256 * 8));
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, inv_scale, found_inf, step_in, step_out);
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, inv_scale, grad_scale, found_inf, step_in, step_out);
     return launch_status("adam_step_kernel");
+}
+
+extern "C" int nerfx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               float lr, float beta1, float beta2, float eps, float weight_decay,
+                               const float* inv_scale, const float* found_inf, const float* step_in,
+                               float* step_out, void* stream) {
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, inv_scale, nullptr,
+                       found_inf, step_in, step_out, stream);
+}
+
+extern "C" int nerfx_adam_step_scaled(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                      float lr, float beta1, float beta2, float eps, float weight_decay,
+                                      const float* grad_scale, const float* found_inf, const float* step_in,
+                                      float* step_out, void* stream) {
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, nullptr, grad_scale,
+                       found_inf, step_in, step_out, stream);
 }
 
 // ---- distillation loss (distill.py:120-130) ---------------------------------------------------

@@ -446,8 +446,8 @@ class _FieldFunction(torch.autograd.Function):
         arr = (C.c_void_p * len(slots))(*[None if g is None else g.data_ptr() for g in slots])
         if ctx.M > 0:
             with torch.cuda.device(dev):
-                check(lib.nerfx_mlp_bwd(ctx.handle.ptr, ctx.prec, ctx.M, _p(sigma), _p(rgb), _p(g_sigma), _p(g_rgb),
-                                        _p(ctx.ws), ctx.ws_bytes, arr, len(slots), _stream()))
+                check(lib.nerfx_mlp_bwd_checked(ctx.handle.ptr, ctx.prec, ctx.M, _p(sigma), _p(rgb), _p(g_sigma), _p(g_rgb),
+                                                _p(ctx.ws), ctx.ws_bytes, arr, len(slots), _p(GRAD_CHECK), _stream()))
         else:
             grads = [None if g is None else g.zero_() for g in grads]
         ctx.ws = None
@@ -468,6 +468,12 @@ class _CompositeFunction(torch.autograd.Function):
         sigma, rgb, t, rd = ctx.saved_tensors
         g_sigma, g_rgb = composite_bwd(sigma, rgb, t, rd, None, g_rgb_map, g_depth, g_w)
         return g_sigma, g_rgb, None, None
+
+
+# While a tensor (one device float, zeroed by mse_seed) is set here, the backward passes below raise it
+# to 1 when a parameter gradient they write is not finite: the GradScaler's inf check, made by the
+# kernel that writes the gradients instead of by a pass of its own (see nerf_amd.amp).
+GRAD_CHECK = None
 
 
 class _RenderTrainFunction(torch.autograd.Function):
@@ -514,8 +520,9 @@ class _RenderTrainFunction(torch.autograd.Function):
         arr = (C.c_void_p * len(slots))(*[None if g is None else g.data_ptr() for g in slots])
         if B > 0:
             with torch.cuda.device(dev):
-                check(lib.nerfx_render_bwd(ctx.handle.ptr, ctx.prec, _p(rd), B, nc, nf, _p(t), _p(g_rgb_map), _p(g_depth),
-                                           _p(g_w), _p(ctx.ws), ctx.ws_bytes, arr, len(slots), _stream()))
+                check(lib.nerfx_render_bwd_checked(ctx.handle.ptr, ctx.prec, _p(rd), B, nc, nf, _p(t), _p(g_rgb_map),
+                                                   _p(g_depth), _p(g_w), _p(ctx.ws), ctx.ws_bytes, arr, len(slots),
+                                                   _p(GRAD_CHECK), _stream()))
         else:
             grads = [None if g is None else g.zero_() for g in grads]
         ctx.ws = None
@@ -665,19 +672,43 @@ def mse_loss(pred: Tensor, target: Tensor, loss_psnr: Optional[Tensor] = None) -
     return loss_psnr[0]
 
 
+def mse_seed(pred: Tensor, target: Tensor, loss_psnr: Tensor, loss_scale: Optional[Tensor] = None,
+             found_inf: Optional[Tensor] = None) -> Tensor:
+    """d (loss_scale * mse(pred, target)) / d pred, with the unscaled loss and its PSNR written to
+    `loss_psnr` (2 device floats) and `found_inf` (one device float) zeroed, all in one kernel: the part
+    of a step between the render and the backward (reference train.py:77-80) behind a GradScaler."""
+    pred, target = _dev(pred.detach(), "pred"), _dev(target.detach(), "target")
+    assert pred.shape == target.shape, "pred and target shapes differ"
+    seed = torch.empty_like(pred)
+    with torch.cuda.device(pred.device):
+        check(lib.nerfx_mse_loss_scaled(_p(pred), _p(target), pred.numel(), _p(loss_psnr), _p(seed), _p(loss_scale),
+                                        _p(found_inf), _stream()))
+    return seed
+
+
 def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, lr: float, beta1: float,
               beta2: float, eps: float, weight_decay: float, inv_scale: Optional[Tensor],
-              found_inf: Optional[Tensor], step_in: Tensor, step_out: Tensor) -> None:
+              found_inf: Optional[Tensor], step_in: Tensor, step_out: Tensor,
+              grad_scale: Optional[Tensor] = None) -> None:
+    """One Adam update over flat buffers; gradients are multiplied by `inv_scale`, or divided by
+    `grad_scale` (the loss scale itself: no reciprocal kernel in front), when one is given."""
     n = param.numel()
+    assert inv_scale is None or grad_scale is None, "give the inverse scale or the scale, not both"
     for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
             raise RuntimeError(f"adam_step: `{name}` must be a contiguous fp32 ROCm tensor of {n} elements")
-    for name, t in (("inv_scale", inv_scale), ("found_inf", found_inf), ("step_in", step_in), ("step_out", step_out)):
+    for name, t in (("inv_scale", inv_scale), ("grad_scale", grad_scale), ("found_inf", found_inf), ("step_in", step_in),
+                    ("step_out", step_out)):
         if t is not None and not (t.is_cuda and t.device == param.device and t.dtype == torch.float32 and t.numel() == 1):
             raise RuntimeError(f"adam_step: `{name}` must be one fp32 element on {param.device}")
     with torch.cuda.device(param.device):
-        check(lib.nerfx_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lr, beta1, beta2, eps,
-                                  weight_decay, _p(inv_scale), _p(found_inf), _p(step_in), _p(step_out), _stream()))
+        if grad_scale is not None:
+            check(lib.nerfx_adam_step_scaled(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lr, beta1, beta2, eps,
+                                             weight_decay, _p(grad_scale), _p(found_inf), _p(step_in), _p(step_out),
+                                             _stream()))
+        else:
+            check(lib.nerfx_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lr, beta1, beta2, eps,
+                                      weight_decay, _p(inv_scale), _p(found_inf), _p(step_in), _p(step_out), _stream()))
 
 
 def voxel_sample(domain, voxels: int, samples: int, device, rng=None):

@@ -95,6 +95,13 @@ class Adam(torch.optim.Optimizer):
         return int(state["step"][state["which"]].item())
 
     @torch.no_grad()
+    def step_scaled(self, grad_scale: Tensor, found_inf: Tensor) -> None:
+        """`scaler.unscale_(self); scaler.step(self)` (reference train.py:81-83) as one launch: the
+        gradients still carry the loss scale `grad_scale` (the scaler's device float), `found_inf` is the
+        device float the backward raised if a gradient was not finite (nerf_amd.amp)."""
+        self._update(grad_scale, found_inf)
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
@@ -102,6 +109,10 @@ class Adam(torch.optim.Optimizer):
                 loss = closure()
         found_inf = getattr(self, "found_inf", None)        # set by GradScaler.step around this call
         grad_scale = getattr(self, "grad_scale", None)      # None once unscale_ has run
+        self._update(grad_scale, found_inf)
+        return loss
+
+    def _update(self, grad_scale, found_inf):
         for group in self.param_groups:
             params = group["params"]
             state = self.state[params[0]]
@@ -118,14 +129,13 @@ class Adam(torch.optim.Optimizer):
                 grad = state["flat_grad"]
                 for p, v in zip(params, grad.split(state["sizes"])):
                     v.copy_(p.grad.reshape(-1))
-            inv_scale = None if grad_scale is None else grad_scale.to(torch.float32).reciprocal().reshape(1)
+            scale = None if grad_scale is None else grad_scale.to(torch.float32).reshape(1)   # no copy when already fp32
             finf = None if found_inf is None else found_inf.to(torch.float32).reshape(1)
             w = state["which"]
             step = state["step"]
             ops.adam_step(state["flat_param"], grad, state["exp_avg"], state["exp_avg_sq"], group["lr"],
                           group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"],
-                          inv_scale, finf, step[w:w + 1], step[1 - w:2 - w])
+                          None, finf, step[w:w + 1], step[1 - w:2 - w], grad_scale=scale)
             state["which"] = 1 - w
             for p in params:                                # written through raw pointers: tell autograd
                 torch.autograd.graph.increment_version(p)   # and the packed-weight cache of ops.ModelHandle
-        return loss

@@ -12,7 +12,8 @@ is harmless).  Optimizer, scaler, criterion and scheduler are the caller's objec
 Losses and PSNRs are kept on the device and fetched every `LOG_EVERY` steps (and at the end of
 the pass), not with four `.item()` calls per step as the reference does (train.py:94-97): the
 returned lists are the same, the progress bar refreshes less often, and with
-`nerf_amd.optim.Adam` no step waits for the host.
+`nerf_amd.optim.Adam` no step waits for the host; behind a GradScaler that optimizer also takes over
+the scaler's unscale / inf check / skipped step (nerf_amd.amp), with the same results.
 When torch.distributed is initialised with more than one rank, every rank runs this loop on
 its own batches and the gradients are averaged (one flat all-reduce) before `unscale_`.
 """
@@ -20,23 +21,74 @@ from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 import torch
-from torch import device
+from torch import Tensor, device
 from torch.nn import Module
 from torch.nn.utils import clip_grad_norm_
 from torch.optim import Optimizer
 from torch.utils.data import DataLoader, Dataset
 
-from . import ops
+from . import amp, ops
 from .core.model import NeRF
 from .core.renderer import BoundedVolumeRaymarcher as BVR
 from .core.scheduler import Scheduler
 from .data.utils import loaders
-from .distributed import average_gradients
+from .distributed import average_gradients, world
+from .optim import Adam as FlatAdam
 from .utils.history import History
 from .utils.pbar import tqdm
 
 GRAD_NORM_CLIP = 0.
 LOG_EVERY = 32          # steps between fetches of the device-side loss / PSNR log
+
+
+def batch_step(nerf: NeRF, raymarcher: BVR, optim: Optimizer, scheduler: Scheduler, criterion: Module, scaler,
+               C: Tensor, ro: Tensor, rd: Tensor, perturb: bool, log_row: Tensor) -> None:
+    """One optimisation step on one batch that is already on the device (reference train.py:75-86);
+    the loss and its PSNR go to `log_row` (2 device floats).
+
+    With a mean `MSELoss` the loss, the PSNR and the seed of the backward come from one kernel and the
+    graph starts at the rendered colours (no loss node, no fill, no multiplies).  Behind an enabled
+    GradScaler with `nerf_amd.optim.Adam`, in a single process and without gradient clipping, the
+    scaler's four calls cost no launches of their own either (see nerf_amd.amp); otherwise they are
+    made as the reference makes them."""
+    d = ro.device
+    fused_mse = type(criterion) is torch.nn.MSELoss and criterion.reduction == "mean"
+    with torch.autocast("cuda", enabled=scaler.is_enabled()):
+        *_, C_ = raymarcher.render_volume(nerf, nerf, ro, rd, perturb=perturb, train=True)
+        if not fused_mse:
+            loss = criterion(C_, C)
+    scale = None
+    if fused_mse and isinstance(optim, FlatAdam) and GRAD_NORM_CLIP <= 0. and world()[1] == 1:
+        scale = amp.loss_scale(scaler, d)
+    if scale is not None:                                   # scale / backward / unscale_ / step / update, fused
+        found_inf = torch.empty(1, dtype=torch.float32, device=d)
+        seed = ops.mse_seed(C_, C, log_row, scale, found_inf)
+        ops.GRAD_CHECK = found_inf
+        try:
+            C_.backward(seed)
+        finally:
+            ops.GRAD_CHECK = None
+        optim.step_scaled(scale, found_inf)
+        amp.record_step(scaler, optim, found_inf)
+        scaler.update()
+    else:
+        if fused_mse and not scaler.is_enabled():
+            C_.backward(ops.mse_seed(C_, C, log_row))
+        elif fused_mse:
+            scaler.scale(ops.mse_loss(C_, C, log_row)).backward()
+        else:
+            scaler.scale(loss).backward()
+            with torch.no_grad():
+                log_row[0] = loss.detach()
+                log_row[1] = -10. * torch.log10(loss.detach())
+        average_gradients(nerf)          # data parallel: no-op in a single process
+        scaler.unscale_(optim)
+        if GRAD_NORM_CLIP > 0.:
+            clip_grad_norm_(nerf.parameters(), GRAD_NORM_CLIP)
+        scaler.step(optim)
+        scaler.update()
+    optim.zero_grad(set_to_none=True)
+    scheduler.step()
 
 
 def step(epoch: int, nerf: NeRF, raymarcher: BVR, optim: Optimizer, scheduler: Scheduler, criterion: Module,
@@ -68,32 +120,19 @@ def step(epoch: int, nerf: NeRF, raymarcher: BVR, optim: Optimizer, scheduler: S
     with torch.set_grad_enabled(train):
         for k, (C, ro, rd) in enumerate(batches):
             C, ro, rd = C.to(d), ro.to(d), rd.to(d)
-
-            with torch.autocast("cuda", enabled=scaler.is_enabled()):
-                *_, C_ = raymarcher.render_volume(nerf, nerf, ro, rd, perturb=perturb, train=train)
-                if fused_mse:
-                    loss = ops.mse_loss(C_, C, log[k])
-                else:
-                    loss = criterion(C_, C)
-
             if train:
-                scaler.scale(loss).backward()
-                average_gradients(nerf)          # data parallel: no-op in a single process
-                scaler.unscale_(optim)
-                if GRAD_NORM_CLIP > 0.:
-                    clip_grad_norm_(nerf.parameters(), GRAD_NORM_CLIP)
-                scaler.step(optim)
-                scaler.update()
-                optim.zero_grad(set_to_none=True)
-                scheduler.step()
-
+                batch_step(nerf, raymarcher, optim, scheduler, criterion, scaler, C, ro, rd, perturb, log[k])
                 total_lr += scheduler.lr / len(loader)
                 steps_lr.append(scheduler.lr)
-
-            if not fused_mse:
-                with torch.no_grad():
-                    log[k, 0] = loss.detach()
-                    log[k, 1] = -10. * torch.log10(loss.detach())
+            else:
+                with torch.autocast("cuda", enabled=scaler.is_enabled()):
+                    *_, C_ = raymarcher.render_volume(nerf, nerf, ro, rd, perturb=perturb, train=False)
+                    if fused_mse:
+                        ops.mse_loss(C_, C, log[k])
+                    else:
+                        loss = criterion(C_, C)
+                        log[k, 0] = loss
+                        log[k, 1] = -10. * torch.log10(loss)
             if (k + 1) % LOG_EVERY == 0:
                 fetch(k + 1)
         fetch(len(loader))

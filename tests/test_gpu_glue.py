@@ -180,3 +180,40 @@ def test_train_step_with_fused_glue_matches_torch_glue(ops):
     assert_close(torch.tensor(psnr_a), torch.tensor(psnr_b), rtol=1e-5, atol=1e-5, what="psnrs")
     for k, (a, b) in enumerate(zip(w_a, w_b)):
         assert_close(a, b, rtol=1e-4, atol=2e-6, what=f"weights after 3 steps, tensor {k}")
+
+
+def test_fused_grad_scaler_step_matches_torch_grad_scaler(ops):
+    """nerf_amd.train.step behind an enabled GradScaler, with the flat Adam (the scaler's scale /
+    unscale_ / inf check / step run inside the step's own kernels, nerf_amd.amp) against the same pass
+    with torch's Adam (every scaler call made by torch): five steps of which the third overflows (an
+    infinite target colour).  Same losses, same weights, the overflowing step skipped by both, and the
+    same loss scale afterwards (halved once)."""
+    import nerf_amd.train as T
+    from nerf_amd.core import BoundedVolumeRaymarcher, IndendityScheduler
+    from nerf_amd.optim import Adam
+    meta, gold = load_golden("g7_train_student")
+    g = torch.Generator().manual_seed(23)
+    batches = [tuple(torch.rand(64, 3, generator=g) for _ in range(3)) for _ in range(5)]
+    batches[2][0][7, 1] = float("inf")
+    bvr = BoundedVolumeRaymarcher(2.0, 6.0, 16, 16)
+    ops.set_precision("fp32")                               # same arithmetic on both sides; autocast only picks bf16
+    results = []
+    for fused in (True, False):
+        model = product_model(meta["model"], gold)
+        optim = (Adam if fused else torch.optim.Adam)(model.parameters(), lr=5e-4, eps=1e-4)
+        sched = IndendityScheduler(optim, 1, 5e-4)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=1000, enabled=True)
+        mse, psnr, lr = T.step(0, model, bvr, optim, sched, torch.nn.MSELoss(), scaler, batches, torch.device("cuda"),
+                               split="train", perturb=False, verbose=False)
+        steps = optim.steps_applied if fused else int(optim.state[next(model.parameters())]["step"])
+        results.append((mse, [p.detach().cpu() for p in model.parameters()], scaler.get_scale(), steps))
+    ops.set_precision(None)
+    (mse_a, w_a, scale_a, steps_a), (mse_b, w_b, scale_b, steps_b) = results
+    assert scale_a == scale_b == 512.0
+    assert steps_a == steps_b == 4
+    assert mse_a[2] == float("inf") and mse_b[2] == float("inf")
+    keep = [0, 1, 3, 4]
+    assert_close(torch.tensor(mse_a)[keep], torch.tensor(mse_b)[keep], rtol=1e-5, atol=0, what="losses")
+    for k, (a, b) in enumerate(zip(w_a, w_b)):
+        assert bool(torch.isfinite(a).all())
+        assert_close(a, b, rtol=1e-4, atol=2e-6, what=f"weights after 5 steps (one skipped), tensor {k}")

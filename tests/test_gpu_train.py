@@ -359,6 +359,10 @@ def test_config3_bf16_step_through_train_step(ops):
             seen.update({k: p.grad.detach().clone() for k, p in model.named_parameters()})
             return super().step(closure)
 
+        def step_scaled(self, grad_scale, found_inf):       # the scaler's work is fused in: still scaled here
+            seen.update({k: p.grad.detach() / grad_scale for k, p in model.named_parameters()})
+            return super().step_scaled(grad_scale, found_inf)
+
     optim = RecordingAdam(model.parameters(), lr=lr, eps=eps)
     sched = IndendityScheduler(optim, 1, lr)
     scaler = torch.amp.GradScaler("cuda", init_scale=65536.0, enabled=True)
