@@ -24,6 +24,8 @@ Sub-records on the same JSON line (each timed in a region of its own, after `val
   * `fp32`: the same step with exact-fp32 MFMA contractions (N = 1 only, 3 steps);
   * `train`: 4,096-ray optimisation steps per GPU (render train=True with perturb, fused MSE,
     backward, one flat gradient all-reduce for N > 1, unscale, Adam), ms per step;
+  * `other` (N = 1 only): the reference's other model shapes and its published table's three rows through
+    the same path, 3 frames each (see other_leg);
   * `cpu_baseline` (N = 1 only): the CPU oracle renders the reference's own 100x100 case on the
     host cores, executing the colour head in the coarse pass as the reference does.
 
@@ -256,6 +258,68 @@ def train_leg(args, model, bvr, dev, rank, world, dist, prec, steps, warmup):
             "final_loss": loss}
 
 
+def flop_per_sample(e_x, e_d, width, depth, resid, density_only=False):
+    """Algorithmic FLOP (2 per multiply-add, unpadded) of one sample through NeRF.forward (model.py:68-78)."""
+    hd = depth // 2
+    mac = e_x * width + (hd - 1) * width * width + (width + (e_x if resid else 0)) * width + (hd - 1) * width * width + width
+    if not density_only:
+        mac += width * width + (e_d + width) * (width // 2) + (width // 2) * 3
+    return 2 * mac
+
+
+def other_leg(args, dev, fence):
+    """The reference's other model shapes through the same render path, bf16, 3 timed frames each after
+    one warm-up frame (parity cases measured on the side, not the headline): its Fourier-feature variant
+    and the distilled student on the 800x800 frame, the three rows of the reference's published table
+    (README.md:261-266: 400x400 frames, its CLI's models -- PE(3,10)/PE(3,4), SiLU: Makefile:9-10,
+    train.py:212-221) and the headline model at the reference's own batch of 16,384 rays (bench.py:234)."""
+    import torch
+    import nerf_amd.ops as ops
+    from nerf_amd.core import BoundedVolumeRaymarcher, FourierFeatures, NeRF, PositionalEncoding
+    PE, FF, SiLU = PositionalEncoding, FourierFeatures, torch.nn.SiLU
+    base = lambda: NeRF(PE(3, 6), PE(3, 6), 256, 4)
+    student = lambda: NeRF(PE(3, 6), PE(3, 6), 32, 2, resid=False)
+    cli_nerf = lambda: NeRF(PE(3, 10), PE(3, 4), 256, 8, SiLU)
+    cli_student = lambda: NeRF(PE(3, 10), PE(3, 4), 32, 2, SiLU, resid=False)
+    # name -> (coarse, fine | None = same module, frame side, nc, nf, rays per call, (e_x, e_d, width, depth, resid) of coarse / fine)
+    cases = {
+        "fourier_256x4_800": (lambda: NeRF(FF(3, 256, 32.), FF(3, 64, 16.), 256, 4), None, 800, 64, 64, 65536,
+                              (512, 128, 256, 4, True), None),
+        "student_32x2_800_64+64": (student, None, 800, 64, 64, 65536, (39, 39, 32, 2, False), None),
+        "student_32x2_800_64+128": (student, None, 800, 64, 128, 65536, (39, 39, 32, 2, False), None),
+        "readme_nerf+nerf_400": (cli_nerf, None, 400, 64, 64, 16384, (63, 27, 256, 8, True), None),
+        "readme_student+nerf_400": (cli_student, cli_nerf, 400, 64, 64, 16384, (63, 27, 32, 2, False), (63, 27, 256, 8, True)),
+        "readme_student+student_400": (cli_student, None, 400, 64, 64, 16384, (63, 27, 32, 2, False), None),
+        "base_256x4_800_batch16384": (base, None, 800, 64, 64, 16384, (39, 39, 256, 4, True), None),
+    }
+    out = {}
+    ops.set_precision("bf16")
+    for name, (make_c, make_f, side, nc, nf, batch, dims_c, dims_f) in cases.items():
+        torch.manual_seed(0)
+        coarse = make_c().to(dev)
+        fine = coarse if make_f is None else make_f().to(dev)
+        dims_f = dims_c if dims_f is None else dims_f
+        bvr = BoundedVolumeRaymarcher(TN, TF, nc, nf)
+        n = side * side
+        g = torch.Generator(device=dev).manual_seed(3)
+        ro, rd = torch.rand(n, 3, device=dev, generator=g), torch.rand(n, 3, device=dev, generator=g)
+
+        def frame():
+            for s in range(0, n, batch):
+                bvr.render_volume(coarse, fine, ro[s:s + batch], rd[s:s + batch])
+
+        with torch.no_grad():
+            frame()
+            dt, series = time_region(frame, 3, fence)
+        flop = n * (nc * flop_per_sample(*dims_c, density_only=True) + (nc + nf) * flop_per_sample(*dims_f))
+        out[name] = {"ms_per_frame": dt / 3 * 1e3, "rays_per_s": 3 * n / dt, "frame": f"{side}x{side}", "samples": f"{nc}+{nf}",
+                     "rays_per_call": batch, "tflops": flop / (dt / 3) / 1e12, "mfma_frac": flop / (dt / 3) / 1e12 / PEAK_TFLOPS["bf16"],
+                     "step_ms": {k: v for k, v in spread(series).items() if k != "series"}}
+        del coarse, fine
+    ops.set_precision(None)
+    return out
+
+
 # ---- one rank --------------------------------------------------------------------------------
 def dry_run(args, rank, world):
     """Launcher, process group, ray sharding, gathers and the JSON line on CPU tensors, with a
@@ -336,6 +400,7 @@ def run_rank(args):
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
                 "config": {"workload": "4,096-ray optimisation step per GPU, " + WORKLOAD + ", perturb on, MSELoss, Adam ("
                                        + args.optim + "), GradScaler with bf16", "parallelism": f"data-parallel x{world}"},
+                "step_ms": rec["step_ms"],
                 "roofline": dict(rec["roofline"], traffic=None), "final_loss": rec["final_loss"]}), flush=True)
         if world > 1:
             dist.destroy_process_group()
@@ -428,6 +493,8 @@ def run_rank(args):
         rec = train_leg(args, model, bvr, dev, rank, world, dist, args.prec, 20, 5)
         if rank == 0:
             result["train"] = rec
+    if world == 1 and not args.no_other:
+        result["other"] = other_leg(args, dev, fence)
     ops.set_precision(None)
     if rank == 0:
         if world == 1 and not args.no_cpu:
@@ -450,6 +517,7 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 sub-record")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-record")
     ap.add_argument("--no-roofline", action="store_true", help="skip the staged passes (per-kernel events)")
+    ap.add_argument("--no-other", action="store_true", help="skip the other model shapes (sub-record `other`)")
     ap.add_argument("--optim", choices=("fused", "torch"), default="fused", help="Adam implementation of the training leg")
     ap.add_argument("--mode", choices=("render", "train"), default="render",
                     help="render: the headline metric; train: 4,096-ray optimisation steps as the primary record")

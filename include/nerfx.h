@@ -366,6 +366,12 @@ void nerfx_debug_set_m16(int enable);
  * per wavefront; enable = 0 keeps it on the general one-ray-per-wavefront kernel (same bits), for A/B
  * timing and for the test that holds the two against each other.  Process-wide; default on. */
 void nerfx_debug_set_k4_fast(int enable);
+/* No counterpart in the reference.  bf16 render passes of narrow models (width 16 or 32, depth 2, no
+ * skip connection: the distilled student of distill.py:193-195) run in one kernel per pass with the
+ * compositor as its epilogue; enable = 0 keeps them on the general kernels (same results within the
+ * bf16 bar), for A/B timing and for the test that holds the two against each other.  Process-wide;
+ * default on. */
+void nerfx_debug_set_narrow(int enable);
 
 #ifdef __cplusplus
 }

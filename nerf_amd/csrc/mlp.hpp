@@ -35,6 +35,17 @@ struct RingGeometry {
 // registers).
 using RingBf16 = RingGeometry<8, 8, 4, 1>;
 using RingFp32 = RingGeometry<4, 16, 12, 1>;
+// The two bf16 kernels that write a training tape (training forward, backward chain): a hand-over's
+// wait also sits out every tape store the wave issued before the refill it waits for (one counter,
+// retired in issue order), so how far the refills run ahead is how long a store may take.
+#ifndef NERFX_TRAIN_RING
+#define NERFX_TRAIN_RING 8, 4
+#endif
+#ifndef NERFX_BWD_RING
+#define NERFX_BWD_RING 8, 4
+#endif
+using RingBf16Train = RingGeometry<8, NERFX_TRAIN_RING, 1>;
+using RingBf16Bwd = RingGeometry<8, NERFX_BWD_RING, 1>;
 // bf16 kernels keep each wave's positional-encoding B operands (ENC_BLOCK k-units) in LDS.
 constexpr int STASH_BYTES_PER_WAVE = 4 * 1024;
 constexpr int ENC_BLOCK = 4;                    // encoder k-units come in multiples of this
@@ -204,6 +215,8 @@ inline uint64_t tape_m_pad(int64_t n_points) { return ((uint64_t)n_points + 255)
 
 }  // namespace nerfx
 
+#include "narrow.hpp"
+
 // The opaque handle of include/nerfx.h.
 struct nerfx_model {
     nerfx::ModelPlan plan[nerfx::N_LAYOUTS];          // indexed by NERFX_PREC_* / NERFX_LAYOUT_M16
@@ -223,6 +236,8 @@ struct nerfx_model {
     uint32_t* nan_flags_dev;
     uint32_t pack_epoch;
     const uint32_t* nan_flag() const { return nan_flags_dev + (pack_epoch & 1); }
+    nerfx::NarrowPlan narrow;          // narrow.hpp: models the whole-ray kernel takes (narrow.ok), and their
+    void* narrow_dev;                  // packed block
     int n_tensors;
     int device;
 };

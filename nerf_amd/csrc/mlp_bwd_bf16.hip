@@ -2,6 +2,6 @@
 #include "mlp_bwd_impl.hpp"
 namespace nerfx {
 int launch_mlp_bwd_bf16(int activ, int wt, const BwdArgs& a, hipStream_t s) {
-    return launch_bwd_activation<NERFX_PREC_BF16, RingBf16>(activ, wt, a, s);
+    return launch_bwd_activation<NERFX_PREC_BF16, RingBf16Bwd>(activ, wt, a, s);
 }
 }  // namespace nerfx

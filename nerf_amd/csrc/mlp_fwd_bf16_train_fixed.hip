@@ -2,6 +2,6 @@
 #include "mlp_fwd_impl.hpp"
 namespace nerfx {
 int launch_mlp_bf16_train_fixed(int activ, int hd, const MlpArgs& a, hipStream_t s) {
-    return launch_fixed_depth<NERFX_PREC_BF16, RingBf16, true>(activ, hd, a, s);
+    return launch_fixed_depth<NERFX_PREC_BF16, RingBf16Train, true>(activ, hd, a, s);
 }
 }  // namespace nerfx

@@ -8,6 +8,7 @@
 namespace nerfx {
 
 int wgrad_tasks_create(nerfx_model* m);             // mlp_wgrad.hip
+int narrow_pack(const NarrowPlan& p, const float* const* tensors, void* dst, hipStream_t stream);   // narrow.hip
 
 int make_plan(const nerfx_model_desc_t& d, int layout, ModelPlan& p) {
     const int prec = layout_prec(layout);
@@ -297,6 +298,8 @@ static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipSt
     a.nan_set = m->nan_flags_dev + (m->pack_epoch & 1);
     a.nan_clear = m->nan_flags_dev + ((m->pack_epoch + 1) & 1);
     hipLaunchKernelGGL(pack_model_kernel, dim3(64, a.n_jobs + a.n_vec), dim3(256), 0, stream, a);
+    if (bf16 && m->narrow.ok)                                          // the whole-ray kernel's block (bf16 only)
+        if (int rc = narrow_pack(m->narrow, tensors, m->narrow_dev, stream)) return rc;
     auto table = [&](const float* src, int kind, int n, int off) {
         const int entries = enc_pair_slots(kind, n);
         hipLaunchKernelGGL(pack_pair_table_kernel, dim3((entries + 255) / 256), dim3(256), 0, stream, src, kind, n, entries,
@@ -323,6 +326,7 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
         if (int e = make_plan(*desc, prec, m->plan[prec])) { delete m; return e; }
     m->has_m16 = m16_supported(*desc);
     m->has_encmajor = encmajor_supported(*desc);
+    m->narrow = narrow_plan(*desc);
     m->n_tensors = 2 + 2 * desc->depth + 8;
     if (n_tensors != m->n_tensors) {
         const int want = m->n_tensors;
@@ -338,6 +342,7 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
     for (int prec = 0; prec < 2 && e == hipSuccess; ++prec)
         e = hipMalloc(&m->stream_bwd_dev[prec], (size_t)m->plan[prec].bwd_units * UNIT_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&m->const_dev, (size_t)m->plan[0].const_floats * sizeof(float));
+    if (e == hipSuccess && m->narrow.ok) e = hipMalloc(&m->narrow_dev, (size_t)m->narrow.bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&m->nan_flags_dev, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(m->nan_flags_dev, 0, 2 * sizeof(uint32_t));
     if (e != hipSuccess) {
@@ -389,5 +394,6 @@ extern "C" void nerfx_model_destroy(nerfx_model_t* m) {
         if (m->plans_dev[prec]) (void)hipFree(m->plans_dev[prec]);
     if (m->const_dev) (void)hipFree(m->const_dev);
     if (m->nan_flags_dev) (void)hipFree(m->nan_flags_dev);
+    if (m->narrow_dev) (void)hipFree(m->narrow_dev);
     delete m;
 }

@@ -63,6 +63,9 @@ int sample_t_launch(const float* rd, int64_t n_rays, float tn, float tf, int n_s
                     float* t, float* delta, hipStream_t stream);
 int pdf_sample_launch(const float* t_c, const float* w_c, int64_t n_rays, int nc, int nf, const float* u, const Rng& rng,
                       float* t_sorted, float* cdf, int64_t* idx, float* t_pdf, hipStream_t stream);
+bool narrow_enabled();
+int narrow_render_pass(const nerfx_model* model, const float* ro, const float* rd, const float* t, float tn, float tf,
+                       float* t_out, int64_t n_rays, int n, float* weights, float* rgb_map, float* depth, hipStream_t stream);
 }  // namespace nerfx
 
 namespace {
@@ -78,7 +81,11 @@ int render_sequence(const nerfx_model_t* coarse, const nerfx_model_t* fine, int 
     auto draw = [&](uint32_t which, const float* given) {
         return (rng && !given) ? Rng{rng->seed, rng->offset, which, 1} : Rng{};
     };
+    // Narrow models (narrow.hpp) render a pass in ONE kernel, bf16 inference only: densities and colours
+    // stay in registers and the compositor is that kernel's epilogue.
+    auto whole_ray = [&](const nerfx_model_t* m) { return !tape && precision == NERFX_PREC_BF16 && m->narrow.ok && narrow_enabled(); };
     auto last_pass = [&](const nerfx_model_t* m, int n) -> int {     // MLP with colour on the final samples + composite
+        if (whole_ray(m)) return narrow_render_pass(m, ro, rd, t, tn, tf, nullptr, n_rays, n, weights, rgb_map, depth_map, (hipStream_t)stream);
         int rc = tape ? nerfx_mlp_fwd_train_rays(m, precision, ro, rd, t, n_rays, n, w.sigma_f, w.rgb_f, tape->ws, tape->bytes, stream)
                       : nerfx_mlp_fwd_rays(m, precision, ro, rd, t, n_rays, n, w.sigma_f, w.rgb_f, stream);
         if (rc) return rc;
@@ -90,9 +97,16 @@ int render_sequence(const nerfx_model_t* coarse, const nerfx_model_t* fine, int 
         return last_pass(coarse, nc);
     }
     // coarse pass, density only (renderer.py:134; the colour head's output is unused there)
-    if ((rc = sample_t_launch(rd, n_rays, tn, tf, nc, u_c, draw(0, u_c), w.t_c, nullptr, (hipStream_t)stream))) return rc;
-    if ((rc = nerfx_mlp_fwd_rays(coarse, precision, ro, rd, w.t_c, n_rays, nc, w.sigma_c, nullptr, stream))) return rc;
-    if ((rc = nerfx_composite_fwd(w.sigma_c, nullptr, w.t_c, rd, nullptr, n_rays, nc, w.w_c, nullptr, nullptr, stream))) return rc;
+    const bool plain_t = !u_c && !rng;                      // perturb off: the whole-ray kernel makes its own z values
+    if (!(whole_ray(coarse) && plain_t))
+        if ((rc = sample_t_launch(rd, n_rays, tn, tf, nc, u_c, draw(0, u_c), w.t_c, nullptr, (hipStream_t)stream))) return rc;
+    if (whole_ray(coarse)) {
+        if ((rc = narrow_render_pass(coarse, ro, rd, plain_t ? nullptr : w.t_c, tn, tf, w.t_c, n_rays, nc, w.w_c, nullptr, nullptr,
+                                     (hipStream_t)stream))) return rc;
+    } else {
+        if ((rc = nerfx_mlp_fwd_rays(coarse, precision, ro, rd, w.t_c, n_rays, nc, w.sigma_c, nullptr, stream))) return rc;
+        if ((rc = nerfx_composite_fwd(w.sigma_c, nullptr, w.t_c, rd, nullptr, n_rays, nc, w.w_c, nullptr, nullptr, stream))) return rc;
+    }
     // importance sampling + merge (renderer.py:135)
     if ((rc = pdf_sample_launch(w.t_c, w.w_c, n_rays, nc, nf, u_f, draw(1, u_f), t, nullptr, nullptr, nullptr, (hipStream_t)stream))) return rc;
     // fine pass on all nc + nf samples (renderer.py:138-142) and depth (renderer.py:203)

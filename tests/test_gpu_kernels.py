@@ -862,3 +862,39 @@ def test_nan_inputs_and_parameters_poison_the_outputs(ops, kernel, where):
             sigma, rgb = model(x.cuda(), d.cuda())
         ops.set_precision(None)
         assert bool(torch.isfinite(sigma).all()) and bool(torch.isfinite(rgb).all()), "outputs stay poisoned after the NaN is gone"
+
+
+@pytest.mark.parametrize("name", ["g3_mlp_student", "g3_mlp_tiny16"])
+@pytest.mark.parametrize("nc,nf", [(64, 128), (64, 64), (16, 16), (40, 0), (33, 31), (5, 3)])
+def test_whole_ray_kernel_of_narrow_models(ops, name, nc, nf):
+    """bf16 renders of the narrow models (one kernel per pass: encode -> layers -> heads -> compositor,
+    nothing per-sample through memory but z values and weights) against the same render on the general
+    kernels (MLP kernel + compositor kernel) and against the CPU oracle: ragged sample counts (blocks
+    of 32 partly filled), coarse-only mode, jitter."""
+    from nerf_amd import _lib
+    from nerf_amd.core import BoundedVolumeRaymarcher
+    meta, g = load_golden(name)
+    model = product_model(meta, g)
+    bvr = BoundedVolumeRaymarcher(2.0, 6.0, nc, nf)
+    gen = torch.Generator().manual_seed(41)
+    B = 1037
+    ro, rd = torch.rand(B, 3, generator=gen), torch.rand(B, 3, generator=gen) + 0.05
+    u_c, u_f = torch.rand(B, nc, generator=gen), (torch.rand(B, nf, generator=gen) if nf else None)
+    h = ops.handle_for(model)
+    out = {}
+    try:
+        for narrow in (1, 0):
+            _lib.lib.nerfx_debug_set_narrow(narrow)
+            out[narrow] = ops.render(h, h if nf else None, ro.cuda(), rd.cuda(), 2.0, 6.0, nc, nf, u_c.cuda(),
+                                     None if u_f is None else u_f.cuda(), prec=_lib.PREC_BF16)
+    finally:
+        _lib.lib.nerfx_debug_set_narrow(1)
+    om = oracle_model(meta, g)
+    with torch.no_grad():
+        t_ref, w_ref, d_ref, c_ref = O.render_volume(om, om, ro, rd, 2.0, 6.0, nc, nf, u_c, u_f)
+    for label, other in (("general kernels", [x.cpu() for x in out[0]]), ("oracle", [t_ref, w_ref, d_ref, c_ref])):
+        t, w, d, c = (x.cpu() for x in out[1])
+        assert_close(c, other[3], rtol=0, atol=1e-2, what=f"rgb_map vs {label}")
+        assert_close(d, other[2], rtol=2e-2, atol=2e-2, what=f"depth vs {label}")
+        assert_close(w, other[1], rtol=0, atol=2e-2, what=f"weights vs {label}")
+    assert bool((out[1][1].sum(-1) <= 1.0 + 1e-4).all())
