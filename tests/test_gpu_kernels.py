@@ -865,12 +865,15 @@ def test_nan_inputs_and_parameters_poison_the_outputs(ops, kernel, where):
 
 
 @pytest.mark.parametrize("name", ["g3_mlp_student", "g3_mlp_tiny16"])
-@pytest.mark.parametrize("nc,nf", [(64, 128), (64, 64), (16, 16), (40, 0), (33, 31), (5, 3)])
-def test_whole_ray_kernel_of_narrow_models(ops, name, nc, nf):
+@pytest.mark.parametrize("nc,nf,far", [(64, 128, False), (64, 64, False), (16, 16, False), (40, 0, False), (33, 31, False),
+                                       (5, 3, False), (64, 64, True), (1, 0, False)])
+def test_whole_ray_kernel_of_narrow_models(ops, name, nc, nf, far):
     """bf16 renders of the narrow models (one kernel per pass: encode -> layers -> heads -> compositor,
     nothing per-sample through memory but z values and weights) against the same render on the general
     kernels (MLP kernel + compositor kernel) and against the CPU oracle: ragged sample counts (blocks
-    of 32 partly filled), coarse-only mode, jitter."""
+    of 32 partly filled), coarse-only mode, jitter, a single sample per ray; `far`: origins far enough
+    out that the encoder's angles leave the range the kernel takes without wrapping them (its other
+    code path; the first three rays stay near, so one launch runs both)."""
     from nerf_amd import _lib
     from nerf_amd.core import BoundedVolumeRaymarcher
     meta, g = load_golden(name)
@@ -879,6 +882,8 @@ def test_whole_ray_kernel_of_narrow_models(ops, name, nc, nf):
     gen = torch.Generator().manual_seed(41)
     B = 1037
     ro, rd = torch.rand(B, 3, generator=gen), torch.rand(B, 3, generator=gen) + 0.05
+    if far:
+        ro[3:] = ro[3:] * 60.0 - 30.0
     u_c, u_f = torch.rand(B, nc, generator=gen), (torch.rand(B, nf, generator=gen) if nf else None)
     h = ops.handle_for(model)
     out = {}
