@@ -391,6 +391,13 @@ def run_rank(args):
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         return t_max.item()
 
+    if args.only_other:                                      # diagnostic: just the other model shapes
+        def fence_():
+            torch.cuda.synchronize()
+        with torch.no_grad():
+            print(json.dumps({"other": other_leg(args, dev, fence_)}), flush=True)
+        return 0
+
     if args.mode == "train":
         rec = train_leg(args, model, bvr, dev, rank, world, dist, args.prec, args.steps, args.warmup)
         if rank == 0:
@@ -518,6 +525,7 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the training-step sub-record")
     ap.add_argument("--no-roofline", action="store_true", help="skip the staged passes (per-kernel events)")
     ap.add_argument("--no-other", action="store_true", help="skip the other model shapes (sub-record `other`)")
+    ap.add_argument("--only-other", action="store_true", help="diagnostic: run only the `other` sub-record")
     ap.add_argument("--optim", choices=("fused", "torch"), default="fused", help="Adam implementation of the training leg")
     ap.add_argument("--mode", choices=("render", "train"), default="render",
                     help="render: the headline metric; train: 4,096-ray optimisation steps as the primary record")
