@@ -168,6 +168,7 @@ __device__ __forceinline__ void narrow_encode(lds_f4_t tab, bool positional, int
                 if (4 * u + 2 * j < PX) {
                     const f32x4 a = tab[((2 * u + j) * 2 + h) * 2], b = tab[((2 * u + j) * 2 + h) * 2 + 1];
                     const f32x2 cx = {a[0], a[1]}, cy = {a[2], a[3]}, cz = {b[0], b[1]};
+                    // (packed: 2.23 against 2.28 ms per frame with one fma chain per position)
                     const f32x2 rev = __builtin_elementwise_fma(z2, cz, __builtin_elementwise_fma(y2, cy, x2 * cx));
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
