@@ -197,6 +197,16 @@ int nerfx_pdf_sample(const float* t_c, const float* w_c, int64_t n_rays, int nc,
                      const float* u, float* t_sorted, float* cdf, int64_t* idx, float* t_pdf,
                      void* stream);
 
+/* The coarse pass's weights and K4 in one call: raymarch_volume's weights (renderer.py:50-55, with
+ * segment_lengths, ray.py:60-66) on the coarse densities sigma_c (B, nc), then pdf_z_values and the
+ * merge of pdf_rays (ray.py:158-188, :220-223) as nerfx_pdf_sample.  Same results, bit for bit, as
+ * nerfx_composite_fwd(sigma_c, NULL, t_c, rd, ...) followed by nerfx_pdf_sample.  With nc = nf = 64
+ * and 16-byte aligned arrays it is one kernel and the weights never reach memory; otherwise the two
+ * kernels run with the weights in `w_scratch` (B, nc), which may be NULL only in the first case. */
+int nerfx_coarse_pdf_sample(const float* sigma_c, const float* t_c, const float* rd, int64_t n_rays,
+                            int nc, int nf, const float* u, float* w_scratch, float* t_sorted,
+                            void* stream);
+
 /* torch.searchsorted(cdf, u, right=True) (ray.py:174) on caller-supplied rows:
  * cdf (B, n_cdf) ascending, u (B, n_u) -> idx int64 (B, n_u).  Bit-exact. */
 int nerfx_searchsorted_right(const float* cdf, const float* u, int64_t n_rows, int n_cdf,

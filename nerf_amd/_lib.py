@@ -56,6 +56,7 @@ SIGNATURES = {
     "nerfx_composite_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p]),
     "nerfx_segment_lengths": (_i, [_p, _p, _l, _i, _p, _p]),
     "nerfx_pdf_sample": (_i, [_p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "nerfx_coarse_pdf_sample": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p, _p]),
     "nerfx_searchsorted_right": (_i, [_p, _p, _l, _i, _i, _p, _p]),
     "nerfx_orbit_poses": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _p, _p]),
     "nerfx_pinhole_directions": (_i, [_i, _i, _f, _p, _p]),

@@ -109,6 +109,7 @@ __device__ __forceinline__ float stratified_at(float lo, float hi, int n, int i,
     return __fadd_rn(a, __fmul_rn(__fsub_rn(b, a), u));
 }
 __device__ __forceinline__ float norm3(float x, float y, float z) {
+#pragma clang fp contract(off)                      // the same bits at every call site
     return sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
 }
 #endif

@@ -5,12 +5,11 @@
 // transmittance is an in-lane running product followed by a cross-lane product scan inside the
 // group, and the ray sums are group reductions.  The kernels are HBM-bound: every input is
 // read once and every output written once.
-#include "common.hpp"
+#include "composite.hpp"
 
 namespace nerfx {
 
 constexpr int K3_WAVES = 4;                      // waves per workgroup
-constexpr float K3_EPS = 1e-10f;                 // renderer.py:48
 
 // A ray is owned by a GROUP of LPR consecutive lanes (LPR = 16: four rays per wavefront, 32: two, 64: one);
 // all cross-lane steps stay inside the group.
@@ -19,18 +18,6 @@ __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
     for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, LPR);
     return v;
-}
-// Exclusive product scan across the group (gl = lane index inside the group).
-template <int LPR>
-__device__ __forceinline__ float group_excl_prod(float v, int gl) {
-    float inc = v;
-#pragma unroll
-    for (int off = 1; off < LPR; off <<= 1) {
-        const float o = __shfl_up(inc, off, LPR);
-        if (gl >= off) inc *= o;
-    }
-    const float prev = __shfl_up(inc, 1, LPR);
-    return gl == 0 ? 1.0f : prev;
 }
 // Exclusive suffix sum across the group (sum over lanes after this one).
 template <int LPR>
@@ -143,32 +130,14 @@ struct RaySlice {
             for (int e = 0; e < EPL; ++e) t[e] = 0.0f;
         if (delta_g) {
             load_slice<EPL>(delta_g + base + i0, valid, vec, delta);
+            ray_alpha_from_delta<EPL>(sigma, delta, valid, alpha, x);
         } else {
-            // ray.py:62-65: forward difference, 1e10 behind the last sample, times |rd|
             const float len = norm3(rd_g[3 * ray], rd_g[3 * ray + 1], rd_g[3 * ray + 2]);
-            const float t_next_lane = __shfl_down(t[0], 1, LPR);
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const float tn = e + 1 < EPL ? t[e + 1 < EPL ? e + 1 : e] : t_next_lane;
-                const float d = i0 + e + 1 < n ? __fsub_rn(tn, t[e]) : 1e10f;
-                delta[e] = __fmul_rn(d, len);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            alpha[e] = 1.0f - expf(-(sigma[e] * delta[e]));           // renderer.py:50
-            x[e] = e < valid ? (1.0f - alpha[e]) + K3_EPS : 1.0f;     // renderer.py:51
+            ray_alpha<EPL>(sigma, t, __shfl_down(t[0], 1, LPR), len, i0, n, valid, delta, alpha, x);
         }
     }
     // Transmittance in front of each of this lane's samples.
-    __device__ __forceinline__ void transmittance(float (&T)[EPL], int gl) const {
-        float run = 1.0f;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) run *= x[e];
-        float before = group_excl_prod<LPR>(run, gl);
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) { T[e] = before; before *= x[e]; }
-    }
+    __device__ __forceinline__ void transmittance(float (&T)[EPL], int gl) const { ray_transmittance<EPL, LPR>(x, gl, T); }
 };
 
 template <int EPL, int LPR>
@@ -194,8 +163,7 @@ __global__ __launch_bounds__(64 * K3_WAVES) void composite_fwd_kernel(
         s.load(sigma, t, rd, delta, ray, n, gl);
         float T[EPL];
         s.transmittance(T, gl);
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) w[e] = s.alpha[e] * T[e];        // renderer.py:52
+        ray_weights<EPL>(s.alpha, T, w);                                // renderer.py:52
         if (weights && mine) store_slice<EPL>(weights + base, s.valid, s.vec, w);
         float r = 0.f, g = 0.f, b = 0.f, d = 0.f;
         if (rgb) {

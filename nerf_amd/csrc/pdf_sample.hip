@@ -4,7 +4,7 @@
 // wave scan, `searchsorted(right=True)` by binary search in LDS, the lerp of
 // ray.py:182-186, then the nc + nf values are put in ascending order (rank merge seeded by the
 // bin indices when the fine samples are already ascending, bitonic sort otherwise).
-#include "common.hpp"
+#include "composite.hpp"
 #include "philox.hpp"
 
 #include <atomic>
@@ -323,8 +323,13 @@ __device__ __forceinline__ void group16_sort64(float (&k)[4], int l) {
     across(I8{}, 64); across(I4{}, 64); across(I2{}, 64); across(I1{}, 64); inside(2, 64); inside(1, 64);
 }
 
-template <int MODE>
+// FUSED: `w_c` holds the coarse pass's DENSITIES and the weights are formed here, with the compositor's
+// own arithmetic (composite.hpp: same lane geometry as its four-rays-per-wavefront form, so the same
+// bits), instead of being written by one kernel and read back by this one: renderer.py:95 and :135 in
+// one launch, 1,036 B per ray (densities, z values, direction in; 128 z values out) instead of 1,804.
+template <int MODE, bool FUSED>
 __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __restrict__ t_c, const float* __restrict__ w_c,
+                                                              const float* __restrict__ rd,
                                                               int64_t n_rays, const float* __restrict__ u_g, Rng rng,
                                                               float* __restrict__ t_sorted) {
     // MODE = where the inverse-CDF positions come from: 0 linspace(0, 1, 64), 1 the caller's uniforms,
@@ -347,20 +352,30 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
     float* out = s_out[g];
     int* hist = s_hist[g];
     using f4 = float4;
-    auto fetch = [&](int64_t ray4, f4& tv, f4& wv) {
+    struct Dir { float x, y, z; };
+    auto fetch = [&](int64_t ray4, f4& tv, f4& wv, Dir& dv) {
         const int64_t ray = min(ray4 + g, n_rays - 1);
         tv = *reinterpret_cast<const f4*>(t_c + ray * N + i0);
         wv = *reinterpret_cast<const f4*>(w_c + ray * N + i0);
+        if (FUSED) dv = Dir{rd[3 * ray], rd[3 * ray + 1], rd[3 * ray + 2]};
     };
     f4 t_cur, w_cur, t_nxt = {}, w_nxt = {};
+    Dir d_cur = {}, d_nxt = {};
     (void)u_g; (void)rng;
     const int64_t first = (int64_t)blockIdx.x * 4, stride = (int64_t)gridDim.x * 4;
-    if (first < n_rays) fetch(first, t_cur, w_cur);
+    if (first < n_rays) fetch(first, t_cur, w_cur, d_cur);
     asm volatile("" : "+v"(t_cur.x), "+v"(t_cur.y), "+v"(t_cur.z), "+v"(t_cur.w), "+v"(w_cur.x), "+v"(w_cur.y), "+v"(w_cur.z), "+v"(w_cur.w));
-    if (first + stride < n_rays) fetch(first + stride, t_nxt, w_nxt);
+    if (first + stride < n_rays) fetch(first + stride, t_nxt, w_nxt, d_nxt);
     for (int64_t ray4 = first; ray4 < n_rays; ray4 += stride) {
         const int64_t ray = ray4 + g;
-        const float tq[4] = {t_cur.x, t_cur.y, t_cur.z, t_cur.w}, wq[4] = {w_cur.x, w_cur.y, w_cur.z, w_cur.w};
+        const float tq[4] = {t_cur.x, t_cur.y, t_cur.z, t_cur.w};
+        float wq[4] = {w_cur.x, w_cur.y, w_cur.z, w_cur.w};
+        if (FUSED) {                                                // renderer.py:50-52 on the coarse densities
+            float delta[4], alpha[4], x[4], T[4];
+            ray_alpha<4>(wq, tq, __shfl_down(tq[0], 1, 16), norm3(d_cur.x, d_cur.y, d_cur.z), i0, N, 4, delta, alpha, x);
+            ray_transmittance<4, 16>(x, l, T);
+            ray_weights<4>(alpha, T, wq);
+        }
         // -- pdf and cdf (ray.py:161-164, :220): interior weights + 1e-5, normalised, summed ----
         float wi[4];
 #pragma unroll
@@ -428,9 +443,9 @@ __global__ __launch_bounds__(64) void pdf_sample_64x64_kernel(const float* __res
         }
         // -- the next rays' inputs take over; the ones after them are requested ---------------
         const f4 t_mine = t_cur;
-        t_cur = t_nxt; w_cur = w_nxt;
+        t_cur = t_nxt; w_cur = w_nxt; d_cur = d_nxt;
         asm volatile("" : "+v"(t_cur.x), "+v"(t_cur.y), "+v"(t_cur.z), "+v"(t_cur.w), "+v"(w_cur.x), "+v"(w_cur.y), "+v"(w_cur.z), "+v"(w_cur.w));
-        if (ray4 + 2 * stride < n_rays) fetch(ray4 + 2 * stride, t_nxt, w_nxt);
+        if (ray4 + 2 * stride < n_rays) fetch(ray4 + 2 * stride, t_nxt, w_nxt, d_nxt);
         // -- merge (ray.py:223) ----------------------------------------------------------------
         const float tm[4] = {t_mine.x, t_mine.y, t_mine.z, t_mine.w};
         const float tp_next = row_next(tp[0]);
@@ -537,8 +552,8 @@ int pdf_sample_launch(const float* t_c, const float* w_c, int64_t n_rays, int nc
     const bool aligned = (((uintptr_t)t_c | (uintptr_t)w_c | (uintptr_t)t_sorted) & 15) == 0;
     if (nc == K4F && nf == K4F && !cdf && !idx && !t_pdf && aligned && (((uintptr_t)u & 15) == 0) && k4_fast_enabled()) {
         const int grid4 = (int)std::min<int64_t>((n_rays + 3) / 4, 256 * 64);       // (8,192 workgroups: 3 % slower)
-        auto kern = u ? pdf_sample_64x64_kernel<1> : (rng.on ? pdf_sample_64x64_kernel<2> : pdf_sample_64x64_kernel<0>);
-        hipLaunchKernelGGL(kern, dim3(grid4), dim3(64), 0, stream, t_c, w_c, n_rays, u, rng, t_sorted);
+        auto kern = u ? pdf_sample_64x64_kernel<1, false> : (rng.on ? pdf_sample_64x64_kernel<2, false> : pdf_sample_64x64_kernel<0, false>);
+        hipLaunchKernelGGL(kern, dim3(grid4), dim3(64), 0, stream, t_c, w_c, nullptr, n_rays, u, rng, t_sorted);
         return launch_status("pdf_sample_64x64_kernel");
     }
     const int grid = (int)std::min<int64_t>(n_rays, 256 * 32);
@@ -552,9 +567,33 @@ int pdf_sample_launch(const float* t_c, const float* w_c, int64_t n_rays, int nc
     return launch_status("pdf_sample_kernel");
 }
 
+// Coarse compositing (weights only) + hierarchical sampling.  64 + 64 samples on aligned arrays: one
+// kernel; anything else: the compositor into `w_scratch` (n_rays x nc), then the sampler.
+int coarse_pdf_launch(const float* sigma_c, const float* t_c, const float* rd, int64_t n_rays, int nc, int nf, const float* u,
+                      const Rng& rng, float* w_scratch, float* t_sorted, hipStream_t stream) {
+    NERFX_REQUIRE(n_rays >= 0, "n_rays < 0");
+    if (n_rays == 0) return 0;
+    NERFX_REQUIRE(sigma_c && t_c && rd && t_sorted, "sigma_c / t_c / rd / t_sorted is NULL");
+    const bool aligned = (((uintptr_t)t_c | (uintptr_t)sigma_c | (uintptr_t)t_sorted | (uintptr_t)u) & 15) == 0;
+    if (nc == K4F && nf == K4F && aligned && k4_fast_enabled()) {
+        const int grid4 = (int)std::min<int64_t>((n_rays + 3) / 4, 256 * 64);
+        auto kern = u ? pdf_sample_64x64_kernel<1, true> : (rng.on ? pdf_sample_64x64_kernel<2, true> : pdf_sample_64x64_kernel<0, true>);
+        hipLaunchKernelGGL(kern, dim3(grid4), dim3(64), 0, stream, t_c, sigma_c, rd, n_rays, u, rng, t_sorted);
+        return launch_status("pdf_sample_64x64_kernel (with the coarse compositor)");
+    }
+    NERFX_REQUIRE(w_scratch != nullptr, "w_scratch is NULL (needed unless nc = nf = 64 on 16-byte aligned arrays)");
+    if (int rc = nerfx_composite_fwd(sigma_c, nullptr, t_c, rd, nullptr, n_rays, nc, w_scratch, nullptr, nullptr, stream)) return rc;
+    return pdf_sample_launch(t_c, w_scratch, n_rays, nc, nf, u, rng, t_sorted, nullptr, nullptr, nullptr, stream);
+}
+
 }  // namespace nerfx
 
 using namespace nerfx;
+
+extern "C" int nerfx_coarse_pdf_sample(const float* sigma_c, const float* t_c, const float* rd, int64_t n_rays, int nc, int nf,
+                                       const float* u, float* w_scratch, float* t_sorted, void* stream) {
+    return coarse_pdf_launch(sigma_c, t_c, rd, n_rays, nc, nf, u, Rng{}, w_scratch, t_sorted, (hipStream_t)stream);
+}
 
 extern "C" void nerfx_debug_set_k4_fast(int enable) { g_k4_fast.store(enable ? 1 : 0, std::memory_order_relaxed); }
 

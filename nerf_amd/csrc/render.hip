@@ -63,6 +63,8 @@ int sample_t_launch(const float* rd, int64_t n_rays, float tn, float tf, int n_s
                     float* t, float* delta, hipStream_t stream);
 int pdf_sample_launch(const float* t_c, const float* w_c, int64_t n_rays, int nc, int nf, const float* u, const Rng& rng,
                       float* t_sorted, float* cdf, int64_t* idx, float* t_pdf, hipStream_t stream);
+int coarse_pdf_launch(const float* sigma_c, const float* t_c, const float* rd, int64_t n_rays, int nc, int nf, const float* u,
+                      const Rng& rng, float* w_scratch, float* t_sorted, hipStream_t stream);
 bool narrow_enabled();
 int narrow_render_pass(const nerfx_model* model, const float* ro, const float* rd, const float* t, float tn, float tf,
                        float* t_out, int64_t n_rays, int n, float* weights, float* rgb_map, float* depth, hipStream_t stream);
@@ -100,15 +102,15 @@ int render_sequence(const nerfx_model_t* coarse, const nerfx_model_t* fine, int 
     const bool plain_t = !u_c && !rng;                      // perturb off: the whole-ray kernel makes its own z values
     if (!(whole_ray(coarse) && plain_t))
         if ((rc = sample_t_launch(rd, n_rays, tn, tf, nc, u_c, draw(0, u_c), w.t_c, nullptr, (hipStream_t)stream))) return rc;
+    // then the coarse weights (renderer.py:95) and importance sampling + merge (renderer.py:135)
     if (whole_ray(coarse)) {
         if ((rc = narrow_render_pass(coarse, ro, rd, plain_t ? nullptr : w.t_c, tn, tf, w.t_c, n_rays, nc, w.w_c, nullptr, nullptr,
                                      (hipStream_t)stream))) return rc;
+        if ((rc = pdf_sample_launch(w.t_c, w.w_c, n_rays, nc, nf, u_f, draw(1, u_f), t, nullptr, nullptr, nullptr, (hipStream_t)stream))) return rc;
     } else {
         if ((rc = nerfx_mlp_fwd_rays(coarse, precision, ro, rd, w.t_c, n_rays, nc, w.sigma_c, nullptr, stream))) return rc;
-        if ((rc = nerfx_composite_fwd(w.sigma_c, nullptr, w.t_c, rd, nullptr, n_rays, nc, w.w_c, nullptr, nullptr, stream))) return rc;
+        if ((rc = coarse_pdf_launch(w.sigma_c, w.t_c, rd, n_rays, nc, nf, u_f, draw(1, u_f), w.w_c, t, (hipStream_t)stream))) return rc;
     }
-    // importance sampling + merge (renderer.py:135)
-    if ((rc = pdf_sample_launch(w.t_c, w.w_c, n_rays, nc, nf, u_f, draw(1, u_f), t, nullptr, nullptr, nullptr, (hipStream_t)stream))) return rc;
     // fine pass on all nc + nf samples (renderer.py:138-142) and depth (renderer.py:203)
     return last_pass(fine, nc + nf);
 }

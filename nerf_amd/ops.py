@@ -140,6 +140,18 @@ def pdf_sample(t_c: Tensor, w_c: Tensor, nf: int, u: Optional[Tensor] = None, de
     return (ts, cdf, idx, tp) if debug else ts
 
 
+def coarse_pdf_sample(sigma_c: Tensor, t_c: Tensor, rd: Tensor, nf: int, u: Optional[Tensor] = None) -> Tensor:
+    """Coarse weights (renderer.py:50-55) + pdf_rays' z values (ray.py:158-188, :220-223) -> t_sorted (B, nc+nf)."""
+    sigma_c, t_c, rd = _dev(sigma_c, "sigma_c"), _dev(t_c, "t_c"), _dev(rd, "rd")
+    B, nc = t_c.shape
+    u = None if u is None else _dev(u, "u")
+    ts = torch.empty((B, nc + nf), device=t_c.device)
+    scratch = torch.empty((B, nc), device=t_c.device)
+    with torch.cuda.device(t_c.device):
+        check(lib.nerfx_coarse_pdf_sample(_p(sigma_c), _p(t_c), _p(rd), B, nc, nf, _p(u), _p(scratch), _p(ts), _stream()))
+    return ts
+
+
 def searchsorted_right(cdf: Tensor, u: Tensor) -> Tensor:
     cdf, u = _dev(cdf, "cdf"), _dev(u, "u")
     idx = torch.empty(u.shape, device=u.device, dtype=torch.int64)
@@ -329,8 +341,7 @@ def _render_staged(coarse, fine, ro, rd, tn, tf, nc, nf, u_c, u_f, prec, log):
         return t, w, depth, rgb_map
     t_c = timed("sample", nc, False, lambda: sample_encode(ro, rd, tn, tf, nc, u_c, want_rx=False)["t"])
     sigma_c, _ = timed("mlp", nc, False, lambda: mlp_rays(coarse, ro, rd, t_c, density_only=True, prec=prec))
-    w_c, _, _ = timed("composite", nc, False, lambda: composite_fwd(sigma_c, None, t_c, rd, want_depth=False))
-    t = timed("pdf", nc + nf, False, lambda: pdf_sample(t_c, w_c, nf, u_f))
+    t = timed("pdf", nc + nf, False, lambda: coarse_pdf_sample(sigma_c, t_c, rd, nf, u_f))
     sigma, rgb = timed("mlp", nc + nf, True, lambda: mlp_rays(fine, ro, rd, t, prec=prec))
     w, rgb_map, depth = timed("composite", nc + nf, True, lambda: composite_fwd(sigma, rgb, t, rd))
     return t, w, depth, rgb_map

@@ -804,6 +804,35 @@ def test_k4_four_rays_per_wavefront_same_bits(ops):
                                       f"{int((~same).sum())} values differ, first at {(~same).nonzero()[0].tolist()}")
 
 
+def test_coarse_weights_and_k4_in_one_kernel_same_bits(ops):
+    """nerfx_coarse_pdf_sample forms the coarse weights inside the sampling kernel (64 + 64 samples):
+    bit for bit nerfx_composite_fwd followed by nerfx_pdf_sample, on densities that span empty space,
+    surfaces and opaque blocks, negative, infinite and NaN densities, unnormalised directions, ray
+    counts that leave a wavefront partly empty, with and without the caller's uniforms; other sample
+    counts take the two kernels behind the same entry point."""
+    gen = torch.Generator().manual_seed(11)
+    for B, nc, nf in [(1, 64, 64), (3, 64, 64), (5, 64, 64), (1021, 64, 64), (65536 + 2, 64, 64), (257, 48, 80)]:
+        t_c = torch.sort(torch.rand(B, nc, generator=gen) * 4 + 2, dim=-1).values
+        sigma = torch.randn(B, nc, generator=gen) * 3                    # about half negative: relu'd to zero
+        sigma[B // 2:] = sigma[B // 2:].abs() ** 4                        # surfaces and opaque blocks
+        sigma[-1] = -1.0                                                  # an empty ray: all weights zero
+        rd = torch.randn(B, 3, generator=gen) * 2
+        if B > 4:
+            sigma[1, 10] = float("inf")
+            sigma[2, 20] = float("nan")
+            sigma[3, :] = 1e30
+            t_c[4, 10:20] = t_c[4, 10]                                    # ties: zero-length segments
+        t_c, sigma, rd = t_c.cuda(), sigma.cuda(), rd.cuda()
+        u = torch.rand(B, nf, generator=gen).cuda()
+        for uniforms in (None, u):
+            w_c, _, _ = ops.composite_fwd(sigma, None, t_c, rd, want_depth=False)
+            a = ops.pdf_sample(t_c, w_c, nf, uniforms).cpu()
+            b = ops.coarse_pdf_sample(sigma, t_c, rd, nf, uniforms).cpu()
+            same = (a == b) | (a.isnan() & b.isnan())
+            assert bool(same.all()), (f"B={B} {nc}+{nf}, uniforms {'given' if uniforms is not None else 'none'}: "
+                                      f"{int((~same).sum())} values differ, first at {(~same).nonzero()[0].tolist()}")
+
+
 def _negative_nan():
     return torch.tensor([-1], dtype=torch.int32).view(torch.float32)[0]      # 0xFFFFFFFF: a NaN with its sign bit set
 

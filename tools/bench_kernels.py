@@ -77,6 +77,8 @@ def main():
     w_c = torch.rand(B, 64, device=dev, generator=g)
     s = timed(lambda: ops.pdf_sample(t_c, w_c, 64), it)
     report("K4 pdf_sample (64 + 64)", s, 256 + 256 + 512, "production form: sorted t only")
+    s = timed(lambda: ops.coarse_pdf_sample(sigma64, t_c, rd, 64), it)
+    report("K3 coarse + K4 in one kernel (64 + 64)", s, 256 + 256 + 12 + 512, "densities in, sorted t out; the weights never reach memory")
     for r in rows:
         print(json.dumps(r))
 
