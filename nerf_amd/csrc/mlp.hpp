@@ -151,6 +151,11 @@ struct LayerPlan {
     // Backward-stream layers carry W^T of forward layer `src_layer`: row i, input k is
     // W[k][src_col0 + i] of a weight with leading dimension src_ld.
     int transposed, src_layer, src_ld, src_col0;
+    // M16 stream (inference only): `features` has no activation (model.py:51, :76), so it is folded
+    // into rgb.0 when the stream is packed -- rgb.0(phi_d, W_f h + b_f) = W_d phi_d + (W_r W_f) h +
+    // (W_r b_f + b_r): `absent` marks the layer that is not in the stream, `folded` the one whose
+    // weight is read from the folded copy (nerfx_model::fold_dev).
+    int absent, folded;
 };
 
 struct ModelPlan {
@@ -166,6 +171,7 @@ struct ModelPlan {
     int m16_static;        // M16 layout: both stream lengths are whole ring lengths (see M16_RING_UNITS)
     // const block (floats): [layer biases | sigma w | sigma b | table x | table d]
     int sigw_off, sigb_off, tabx_off, tabd_off, const_floats;
+    int foldb_off;         // const block: rgb.0's bias with the `features` layer folded in (M16 kernel)
     // Backward stream: the input-gradient chain rgb.2 -> rgb.0 -> features -> trunk (last .. 1),
     // each layer the transposed chained block of its forward layer.
     int n_bwd;
@@ -192,11 +198,12 @@ inline bool encmajor_supported(const nerfx_model_desc_t& d) {
 // The M16 kernel's weight ring, in 1 KiB units.  A stream whose length is a whole number of ring
 // lengths puts every unit of a sample block at the same ring position in every block, which makes
 // all of the kernel's ring arithmetic compile-time constants (static mode).  The depth-4 streams fit:
-// 448 units up to the density head = 4 rings; 664 with the colour layers, padded to 672 = 6 rings.
+// 448 units up to the density head = 4 rings; 536 with the colour layers (rgb.0 with `features` folded
+// in, rgb.2), padded to 560 = 5 rings.
 constexpr int M16_RING_UNITS = 112;
-constexpr int M16_STATIC_PAD = 8;               // padding units behind rgb.2 in static mode
+constexpr int M16_STATIC_PAD = 24;              // padding units behind rgb.2 in static mode
 __host__ __device__ constexpr int m16_trunk_units(int hd) { return 32 + (2 * hd - 1) * 128 + 32; }
-__host__ __device__ constexpr int m16_total_units(int hd) { return m16_trunk_units(hd) + 128 + 80 + 8; }
+__host__ __device__ constexpr int m16_total_units(int hd) { return m16_trunk_units(hd) + 80 + 8; }
 __host__ __device__ constexpr bool m16_static_depth(int hd) {
     return m16_trunk_units(hd) % M16_RING_UNITS == 0 && (m16_total_units(hd) + M16_STATIC_PAD) % M16_RING_UNITS == 0;
 }
@@ -229,6 +236,7 @@ struct nerfx_model {
     void* wtasks_dev[2];               // weight-gradient task tables (mlp_wgrad.hip)
     int n_wtasks[2];
     float* const_dev;                  // const block (same for both precisions)
+    float* fold_dev;                   // has_m16: rgb.0's weight [width / 2][in_dim] and bias with `features` folded in (fp32)
     // Two words of NAN_* bits (model.hip): refresh number e records in word e & 1 which outputs a NaN
     // parameter reaches and zeroes the other word for refresh e + 1.  Every refresh reads every
     // parameter (each forward stream holds all layers), so the word of the latest refresh describes

@@ -68,7 +68,7 @@ static int mlp_launch(const nerfx_model_t* model, int precision, const float* p0
     a.ex_kind = p.desc.enc_x_kind; a.ex_n = p.desc.enc_x_n; a.ex_units = p.layer[0].enc_units;
     a.ed_kind = p.desc.enc_d_kind; a.ed_n = p.desc.enc_d_n; a.ed_units = p.layer[2 * p.hd + 1].enc_units;
     a.sigw_off = p.sigw_off; a.sigb_off = p.sigb_off; a.tabx_off = p.tabx_off; a.tabd_off = p.tabd_off;
-    a.const_floats = p.const_floats;
+    a.const_floats = p.const_floats; a.foldb_off = p.foldb_off;
     a.stamps = g_stamps;
     if (tape) {                                                     // training forward: record the tape
         NERFX_REQUIRE(rgb != nullptr, "the training forward needs the colour output");

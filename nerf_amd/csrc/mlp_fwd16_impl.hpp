@@ -481,11 +481,9 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
         }
         st.mark(ST_HEADS);
         if (colour) {
-            int li = LAST + 1;
-            // ---- features: Linear without activation (model.py:51, :76): B -> A ------------
-            linear16<-1, 16, M16_KU, false, M16_ENC_NONE>(ring, cst + li * BIAS_STRIDE, q, B, A, sigw, dot, st, stash, encr);
-            ++li;
-            // ---- rgb.0 on [phi_d | features] (model.py:53, :76): A -> first half of B ------
+            // ---- colour head.  `features` is a Linear without activation (model.py:51, :76), so the
+            // packer has folded it into rgb.0 (LayerPlan::folded): rgb.0 reads [phi_d | h] with h the
+            // last trunk layer's output, B -> first half of A (model.py:53, :76).
             st.mark(ST_EPILOGUE);
             if (one_ray) {
                 // The 32 samples of this wave's block lie on ONE ray, so all of them have the same phi_d:
@@ -515,8 +513,8 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
                 }
             }
             st.mark(ST_ENCODE);
-            linear16<ACT, 8, M16_KU, false, M16_ENC_REGS>(ring, cst + li * BIAS_STRIDE, q, A, B, sigw, dot, st, stash, encr);
-            ++li;
+            linear16<ACT, 8, M16_KU, false, M16_ENC_REGS>(ring, cst + a.foldb_off, q, B, A, sigw, dot, st, stash, encr);
+            constexpr int li = LAST + 3;                            // rgb.2's place among the layers (bias row)
             // ---- rgb.2 (one 16-row tile on 128 inputs: 4 units in one piece) + widened sigmoid
             // (model.py:54, activations.py:18-20)
             st.mark(ST_EPILOGUE);
@@ -529,8 +527,8 @@ __global__ __launch_bounds__(64 * RingBf16::WAVES, RingBf16::WAVES / 4) void mlp
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const Frag16 w = NERFX_LDS_VEC(bf16x8, w0 + k * UNIT_BYTES);
-                out[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, B.f[k][0], out[0], 0, 0, 0);
-                out[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, B.f[k][1], out[1], 0, 0, 0);
+                out[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, A.f[k][0], out[0], 0, 0, 0);
+                out[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, A.f[k][1], out[1], 0, 0, 0);
             }
             st.mark(ST_RUN);
             __builtin_amdgcn_s_barrier();

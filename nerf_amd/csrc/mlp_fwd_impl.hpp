@@ -53,6 +53,7 @@ struct MlpArgs {
     int hd, resid;
     int ex_kind, ex_n, ex_units, ed_kind, ed_n, ed_units;
     int sigw_off, sigb_off, tabx_off, tabd_off, const_floats;
+    int foldb_off;               // const block: rgb.0's bias with `features` folded in (M16 kernel)
     unsigned long long* stamps;  // diagnostic builds: 6 cycle buckets, else NULL
     void* tape;                  // training forward: the tape to record (see Tape), else NULL
     void* tape_signs;            // bf16 training forward: the sign words of the tape (see Tape::signs)

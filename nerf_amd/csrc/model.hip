@@ -47,12 +47,14 @@ int make_plan(const nerfx_model_desc_t& d, int layout, ModelPlan& p) {
             L.n_tiles = 1; L.out_dim = 3; L.chain_tiles = p.rt; L.chain_dim = d.width / 2;
         }
         L.in_dim = L.enc_cols + L.chain_dim;
+        L.absent = layout == NERFX_LAYOUT_M16 && li == 2 * p.hd;    // `features`: folded into rgb.0 (see LayerPlan)
+        L.folded = layout == NERFX_LAYOUT_M16 && li == 2 * p.hd + 1;
         L.group = group_tiles(prec, L.n_tiles);
         L.enc_major = layout == NERFX_STREAM_ENCMAJOR && L.enc_units > 0;
         L.enc_seg = L.enc_units / enc_block(prec) * pad_to_piece(enc_block(prec) * L.group);   // block-wise padding
         L.chain_seg = pad_to_piece(L.chain_tiles * units_per_tile(prec) * L.group);
         L.unit0 = unit;
-        unit += units_of(L);
+        if (!L.absent) unit += units_of(L);
         if (li == 2 * p.hd - 1) p.trunk_units = unit;
     }
     p.total_units = unit;
@@ -91,7 +93,8 @@ int make_plan(const nerfx_model_desc_t& d, int layout, ModelPlan& p) {
     auto table_floats = [](int kind, int n) { return 4 * enc_pair_slots(kind, n); };
     p.tabx_off = p.sigb_off + 4;
     p.tabd_off = p.tabx_off + table_floats(d.enc_x_kind, d.enc_x_n);
-    p.const_floats = p.tabd_off + table_floats(d.enc_d_kind, d.enc_d_n);
+    p.foldb_off = p.tabd_off + table_floats(d.enc_d_kind, d.enc_d_n);
+    p.const_floats = p.foldb_off + BIAS_STRIDE / 2;
     return 0;
 }
 
@@ -186,9 +189,9 @@ enum { NAN_SIGMA = 1, NAN_RGB = 2 };
 // word the NEXT refresh will set bits in; this launch zeroes it (nothing reads it meanwhile).
 struct PackJob { uint8_t layout, plan_index, tensor, nan_class; };
 constexpr int MAX_PACK_JOBS = 6 * MAX_LAYERS;
-constexpr int MAX_VECTORS = MAX_LAYERS + 2;
+constexpr int MAX_VECTORS = MAX_LAYERS + 3;
 struct PackLaunch {
-    const float* tensors[2 + 2 * 16 + 8];
+    const float* tensors[2 + 2 * 16 + 8 + 2];              // the caller's, then the folded rgb.0 weight and bias
     const LayerPlan* plans[N_LAYOUTS];
     void* fwd[N_LAYOUTS];
     void* bwd[N_LAYOUTS];
@@ -226,6 +229,40 @@ __global__ __launch_bounds__(256) void pack_model_kernel(const PackLaunch a) {
     }
     if (saw_nan) atomicOr(a.nan_set, (uint32_t)a.vec_class[v]);
     if (v == 0 && threadIdx.x == 0) *a.nan_clear = 0u;
+}
+
+// rgb.0 with the `features` layer folded in (see LayerPlan::folded): F = [W_r's encoder columns |
+// W_r's chained columns x W_f], fb = b_r + W_r's chained columns x b_f, in the layout of rgb.0.weight.
+// Workgroup (r, g): output row r, columns 64 g .. 64 g + 63 of the product (column `width` is the
+// bias); thread (j, quarter) sums a quarter of the k range in double, in index order, and the four
+// quarters are added in a fixed order: the result does not depend on the launch.
+__global__ __launch_bounds__(256) void fold_colour_head_kernel(const float* __restrict__ Wr, const float* __restrict__ br,
+                                                               const float* __restrict__ Wf, const float* __restrict__ bf,
+                                                               int width, int ed_cols, float* __restrict__ F, float* __restrict__ fb) {
+    __shared__ float s_wr[256];
+    __shared__ double s_part[4][64];
+    const int r = blockIdx.x, ld = ed_cols + width;
+    const float* wr = Wr + (int64_t)r * ld + ed_cols;
+    for (int k = threadIdx.x; k < width; k += 256) s_wr[k] = wr[k];
+    if (blockIdx.y == 0)
+        for (int c = threadIdx.x; c < ed_cols; c += 256) F[(int64_t)r * ld + c] = Wr[(int64_t)r * ld + c];
+    __syncthreads();
+    const int j = threadIdx.x & 63, quarter = threadIdx.x >> 6, c = 64 * blockIdx.y + j;
+    const int k0 = quarter * (width / 4), k1 = k0 + width / 4;      // (width is a multiple of 16)
+    double s = 0.0;
+    if (c < width) {
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) s = fma((double)s_wr[k], (double)Wf[(int64_t)k * width + c], s);
+    } else if (c == width) {
+        for (int k = k0; k < k1; ++k) s = fma((double)s_wr[k], (double)bf[k], s);
+    }
+    s_part[quarter][j] = s;
+    __syncthreads();
+    if (quarter == 0 && c <= width) {
+        const double total = ((s_part[0][j] + s_part[1][j]) + s_part[2][j]) + s_part[3][j];
+        if (c < width) F[(int64_t)r * ld + ed_cols + c] = (float)total;
+        else fb[r] = (float)((double)br[r] + total);
+    }
 }
 
 // Pair-coefficient table of one encoder (see enc_pair_slots): entry k = (cx, cy, cz, 0).
@@ -266,6 +303,16 @@ static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipSt
     for (int i = 0; i < m->n_tensors; ++i) NERFX_REQUIRE(tensors[i] != nullptr, "tensor %d is NULL", i);
     PackLaunch a{};
     for (int i = 0; i < m->n_tensors; ++i) a.tensors[i] = tensors[i];
+    const int fold_w = m->n_tensors, fold_b = m->n_tensors + 1;
+    if (m->has_m16) {
+        const LayerPlan& R = p0.layer[2 * p0.hd + 1];
+        float* fb = m->fold_dev + (size_t)R.out_dim * R.in_dim;
+        hipLaunchKernelGGL(fold_colour_head_kernel, dim3(R.out_dim, (d.width + 1 + 63) / 64), dim3(256), 0, stream, tensors[tensor_index(p0, 2 * p0.hd + 1, false)],
+                           tensors[tensor_index(p0, 2 * p0.hd + 1, true)], tensors[tensor_index(p0, 2 * p0.hd, false)],
+                           tensors[tensor_index(p0, 2 * p0.hd, true)], d.width, R.enc_cols, m->fold_dev, fb);
+        a.tensors[fold_w] = m->fold_dev;
+        a.tensors[fold_b] = fb;
+    }
     auto nan_class = [&](int li) { return (uint8_t)(li < 2 * p0.hd ? NAN_SIGMA | NAN_RGB : NAN_RGB); };
     auto add_stream = [&](int layout, bool with_bwd) {
         const ModelPlan& p = m->plan[layout];
@@ -276,8 +323,9 @@ static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipSt
         for (int li = 0; li < p.n_layers + (with_bwd ? p.n_bwd : 0); ++li) {
             const bool fwd = li < p.n_layers;
             const int src_layer = fwd ? li : p.bwd[li - p.n_layers].src_layer;
-            a.job[a.n_jobs++] = PackJob{(uint8_t)layout, (uint8_t)li, (uint8_t)tensor_index(p, src_layer, false),
-                                        fwd ? nan_class(li) : (uint8_t)0};
+            if (fwd && p.layer[li].absent) continue;
+            const int tensor = fwd && p.layer[li].folded ? fold_w : tensor_index(p, src_layer, false);
+            a.job[a.n_jobs++] = PackJob{(uint8_t)layout, (uint8_t)li, (uint8_t)tensor, fwd ? nan_class(li) : (uint8_t)0};
         }
     };
     const bool bf16 = mask >> NERFX_PREC_BF16 & 1;
@@ -293,6 +341,7 @@ static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipSt
         vec(tensor_index(p0, li, true), p0.layer[li].out_dim, BIAS_STRIDE, li * BIAS_STRIDE, nan_class(li));
     vec(2 + 4 * p0.hd, d.width, BIAS_STRIDE, p0.sigw_off, NAN_SIGMA);
     vec(2 + 4 * p0.hd + 1, 1, 4, p0.sigb_off, NAN_SIGMA);
+    if (m->has_m16) vec(fold_b, d.width / 2, BIAS_STRIDE / 2, p0.foldb_off, NAN_RGB);
     a.consts = m->const_dev;
     m->pack_epoch += 1;                                                // see nerfx_model::nan_flags_dev
     a.nan_set = m->nan_flags_dev + (m->pack_epoch & 1);
@@ -343,6 +392,10 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
         e = hipMalloc(&m->stream_bwd_dev[prec], (size_t)m->plan[prec].bwd_units * UNIT_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&m->const_dev, (size_t)m->plan[0].const_floats * sizeof(float));
     if (e == hipSuccess && m->narrow.ok) e = hipMalloc(&m->narrow_dev, (size_t)m->narrow.bytes);
+    if (e == hipSuccess && m->has_m16) {
+        const LayerPlan& R = m->plan[0].layer[desc->depth + 1];
+        e = hipMalloc((void**)&m->fold_dev, ((size_t)R.out_dim * R.in_dim + R.out_dim) * sizeof(float));
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&m->nan_flags_dev, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(m->nan_flags_dev, 0, 2 * sizeof(uint32_t));
     if (e != hipSuccess) {
@@ -395,5 +448,6 @@ extern "C" void nerfx_model_destroy(nerfx_model_t* m) {
     if (m->const_dev) (void)hipFree(m->const_dev);
     if (m->nan_flags_dev) (void)hipFree(m->nan_flags_dev);
     if (m->narrow_dev) (void)hipFree(m->narrow_dev);
+    if (m->fold_dev) (void)hipFree(m->fold_dev);
     delete m;
 }
