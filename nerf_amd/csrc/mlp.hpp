@@ -134,6 +134,12 @@ __host__ __device__ constexpr int pad_to_piece(int units) {
     return (units + PIECE_UNITS - 1) / PIECE_UNITS * PIECE_UNITS;
 }
 
+// Layouts whose streams carry rgb.0 with the `features` layer folded in (see LayerPlan::folded): all
+// bf16 ones.  fp32 is the exact mode and keeps the reference's two layers: the folded weight rounds once
+// more, and a 4,096-ray training step's gradients, sums that cancel to 1e-5 of their terms, showed it
+// (9e-4 of a gradient's largest entry against a float64 evaluation, where the unfolded fp32 step has 2e-4).
+__host__ __device__ constexpr bool folds_features(int layout) { return layout != NERFX_PREC_FP32; }
+
 // One Linear layer as the kernels see it.
 struct LayerPlan {
     int n_tiles;        // output tiles of rows_per_tile rows
@@ -151,10 +157,11 @@ struct LayerPlan {
     // Backward-stream layers carry W^T of forward layer `src_layer`: row i, input k is
     // W[k][src_col0 + i] of a weight with leading dimension src_ld.
     int transposed, src_layer, src_ld, src_col0;
-    // M16 stream (inference only): `features` has no activation (model.py:51, :76), so it is folded
-    // into rgb.0 when the stream is packed -- rgb.0(phi_d, W_f h + b_f) = W_d phi_d + (W_r W_f) h +
-    // (W_r b_f + b_r): `absent` marks the layer that is not in the stream, `folded` the one whose
-    // weight is read from the folded copy (nerfx_model::fold_dev).
+    // `features` has no activation (model.py:51, :76), so the bf16 kernels do not evaluate it: it is folded
+    // into rgb.0 when their streams are packed (folds_features) -- rgb.0(phi_d, W_f h + b_f) = W_d phi_d + (W_r W_f) h +
+    // (W_r b_f + b_r).  `absent` marks the layer that is in no stream (and has no tape tiles),
+    // `folded` the one whose weight is read from the folded copy (nerfx_model::fold_dev).  Training
+    // differentiates the folded form and unfolds the two layers' gradients afterwards (mlp_wgrad.hip).
     int absent, folded;
 };
 
@@ -172,14 +179,14 @@ struct ModelPlan {
     // const block (floats): [layer biases | sigma w | sigma b | table x | table d]
     int sigw_off, sigb_off, tabx_off, tabd_off, const_floats;
     int foldb_off;         // const block: rgb.0's bias with the `features` layer folded in (M16 kernel)
-    // Backward stream: the input-gradient chain rgb.2 -> rgb.0 -> features -> trunk (last .. 1),
+    // Backward stream: the input-gradient chain rgb.2 -> rgb.0 -> features (fp32 only) -> trunk (last .. 1),
     // each layer the transposed chained block of its forward layer.
     int n_bwd;
     LayerPlan bwd[MAX_LAYERS];
     int64_t bwd_units;
     // Training tape tiles (see Tape in mlp_fwd_impl.hpp).  The pre-activation tape and the
     // gradient tape share one tile map: encoder slots of x and of d (32 per tile), then the output
-    // tiles of every layer but rgb.2, then one "heads" tile (gradient tape only) whose positions
+    // tiles of every layer in the streams but rgb.2, then one "heads" tile (gradient tape only) whose positions
     // 0..2 are the gradients at rgb.2's outputs and position 3 the one at the density head's
     // pre-activation.
     int tape_ex_tile, tape_ed_tile, tape_z_tile[MAX_LAYERS], tape_heads_tile, tape_tiles;
@@ -236,7 +243,28 @@ struct nerfx_model {
     void* wtasks_dev[2];               // weight-gradient task tables (mlp_wgrad.hip)
     int n_wtasks[2];
     float* const_dev;                  // const block (same for both precisions)
-    float* fold_dev;                   // has_m16: rgb.0's weight [width / 2][in_dim] and bias with `features` folded in (fp32)
+    // rgb.0 with `features` folded in (fp32, written by every refresh): weight [width / 2][in_dim], bias
+    // [width / 2]; then what unfolding the gradients needs of the weights as they were at that refresh:
+    // W_f [width][width], b_f [width], W_r's chained columns [width / 2][width]; then the folded layer's
+    // gradient (weight, bias) as the weight-gradient kernels leave it.
+    float* fold_dev;
+    struct FoldSpots { float *w, *b, *wft, *bf, *wr, *gw, *gb; int64_t floats; };
+    FoldSpots fold_spots() const {
+        const nerfx::LayerPlan& R = plan[0].layer[2 * plan[0].hd + 1];
+        const int64_t half = R.out_dim, width = R.chain_dim, ld = R.in_dim;
+        FoldSpots s{};
+        int64_t at = 0;
+        auto take = [&](int64_t n) { float* q = fold_dev ? fold_dev + at : nullptr; at += n; return q; };
+        s.w = take(half * ld);
+        s.b = take(half);
+        s.wft = take(width * width);
+        s.bf = take(width);
+        s.wr = take(half * width);
+        s.gw = take(half * ld);
+        s.gb = take(half);
+        s.floats = at;
+        return s;
+    }
     // Two words of NAN_* bits (model.hip): refresh number e records in word e & 1 which outputs a NaN
     // parameter reaches and zeroes the other word for refresh e + 1.  Every refresh reads every
     // parameter (each forward stream holds all layers), so the word of the latest refresh describes

@@ -27,7 +27,7 @@ struct BwdArgs {
     const float* rgb;            // (M,3) are formed from them
     uint32_t n_points, n_blocks, n_pieces;
     int hd, sigw_off, const_floats;
-    int z_tile[MAX_LAYERS], heads_tile, n_tiles;
+    int z_tile[MAX_LAYERS], heads_tile, n_tiles;   // (bf16: z_tile of the folded-away `features` layer is unused)
 };
 
 template <int PREC, int ACT>
@@ -199,18 +199,28 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
 #pragma unroll
         for (int s = 0; s < P::UPT; ++s) A[s] = P::from_acc(top, s);
         constexpr int S_RT = stores_left<PREC>(RT), S_WT = stores_left<PREC>(WT);
-        linear_bwd<PREC, RG, ACT, RT, 1, false, 0>(ring, h, A, B, zt, gt, a.z_tile[feat + 1], sigw, gs);      // -> rgb.0
-        linear_bwd<PREC, RG, -1, WT, RT, false, S_RT>(ring, h, B, A, zt, gt, a.z_tile[feat], sigw, gs);      // -> features
-        linear_bwd<PREC, RG, ACT, WT, WT, true, S_WT>(ring, h, A, B, zt, gt, a.z_tile[feat - 1], sigw, gs);  // -> last trunk layer
+        // bf16: `features` is folded into rgb.0 in the streams (LayerPlan::folded), so rgb.0's transposed
+        // block maps its gradient straight to the last trunk layer's output, where the density head's
+        // contribution joins it; fp32 walks through `features` as the reference's autograd does.
+        constexpr bool FOLD = folds_features(PREC);
+        linear_bwd<PREC, RG, ACT, RT, 1, false, 0>(ring, h, A, B, zt, gt, a.z_tile[feat + 1], sigw, gs);          // -> rgb.0
+        if constexpr (FOLD) {
+            linear_bwd<PREC, RG, ACT, WT, RT, true, S_RT>(ring, h, B, A, zt, gt, a.z_tile[feat - 1], sigw, gs);  // -> last trunk layer
+        } else {
+            linear_bwd<PREC, RG, -1, WT, RT, false, S_RT>(ring, h, B, A, zt, gt, a.z_tile[feat], sigw, gs);      // -> features
+            linear_bwd<PREC, RG, ACT, WT, WT, true, S_WT>(ring, h, A, B, zt, gt, a.z_tile[feat - 1], sigw, gs);  // -> last trunk layer
+        }
         // trunk layers feat-1 .. 1, each producing the gradient of the layer below it
+        Frag (&X)[HN] = FOLD ? A : B;                               // holds the last trunk layer's gradient
+        Frag (&Y)[HN] = FOLD ? B : A;
         int li = feat - 1;
         if (li >= 1) {
-            linear_bwd<PREC, RG, ACT, WT, WT, false, S_WT>(ring, h, B, A, zt, gt, a.z_tile[li - 1], sigw, gs);
+            linear_bwd<PREC, RG, ACT, WT, WT, false, S_WT>(ring, h, X, Y, zt, gt, a.z_tile[li - 1], sigw, gs);
             --li;
         }
         for (; li >= 2; li -= 2) {
-            linear_bwd<PREC, RG, ACT, WT, WT, false, S_WT>(ring, h, A, B, zt, gt, a.z_tile[li - 1], sigw, gs);
-            linear_bwd<PREC, RG, ACT, WT, WT, false, S_WT>(ring, h, B, A, zt, gt, a.z_tile[li - 2], sigw, gs);
+            linear_bwd<PREC, RG, ACT, WT, WT, false, S_WT>(ring, h, Y, X, zt, gt, a.z_tile[li - 1], sigw, gs);
+            linear_bwd<PREC, RG, ACT, WT, WT, false, S_WT>(ring, h, X, Y, zt, gt, a.z_tile[li - 2], sigw, gs);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

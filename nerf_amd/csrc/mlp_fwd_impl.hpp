@@ -53,7 +53,7 @@ struct MlpArgs {
     int hd, resid;
     int ex_kind, ex_n, ex_units, ed_kind, ed_n, ed_units;
     int sigw_off, sigb_off, tabx_off, tabd_off, const_floats;
-    int foldb_off;               // const block: rgb.0's bias with `features` folded in (M16 kernel)
+    int foldb_off;               // const block: rgb.0's bias with `features` folded in
     unsigned long long* stamps;  // diagnostic builds: 6 cycle buckets, else NULL
     void* tape;                  // training forward: the tape to record (see Tape), else NULL
     void* tape_signs;            // bf16 training forward: the sign words of the tape (see Tape::signs)
@@ -941,23 +941,30 @@ __global__ __launch_bounds__(64 * RG::WAVES, RG::BLOCKS_PER_CU * RG::WAVES / 4) 
         }
         st.mark(ST_HEADS);
         if (colour) {
+            // ---- colour head.  `features` is a Linear without activation (model.py:51, :76): in the bf16
+            // streams the packer has folded it into rgb.0 (LayerPlan::folded), which then reads [phi_d | h]
+            // with h the last trunk layer's output (B -> A, rgb.2 reads A); fp32 evaluates the two layers
+            // as the reference does (B -> A -> B, rgb.2 reads B).
+            constexpr bool FOLD = folds_features(PREC);
             li = last + 1;
-            // ---- features: Linear without activation (model.py:51, :76): B -> A ------------
-            linear<PREC, RG, -1, BIGENC, WT, WT, false, false, TRAIN, S_WT>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li]);
+            if constexpr (!FOLD) linear<PREC, RG, -1, BIGENC, WT, WT, false, false, TRAIN, S_WT>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li]);
             ++li;
-            // ---- rgb.0 on [phi_d | features] (model.py:53, :76): A -> B ---------------------
+            // ---- rgb.0 on [phi_d | features] (model.py:53, :76) -------------------------------
             { st.mark(ST_EPILOGUE); enc.template prepare<BIGENC>(a.ed_kind, a.ed_units, cst + a.tabd_off, h, dx, dy, dz); st.mark(ST_ENCODE); }
             if constexpr (TRAIN && !BIGENC) {
 #pragma unroll
                 for (int u = 0; u < ENC_BLOCK; ++u)
                     if (u < a.ed_units) tape.store_enc(a.tape_ed_tile, u, h, enc.cached[u]);
             }
-            if constexpr (ENCMAJOR) linear_encmajor<RG, ACT, RT, WT, false>(ring, cst + li * BIAS_STRIDE, h, A, B, enc, sigw, st);
-            else linear<PREC, RG, ACT, BIGENC, RT, WT, false, false, TRAIN, S_WT>(ring, cst + li * BIAS_STRIDE, h, A, B, true, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li], a.tape_ed_tile);
+            const lds_floats_t rgb0_bias = FOLD ? cst + a.foldb_off : cst + li * BIAS_STRIDE;
+            Frag (&rgb0_in)[HN] = FOLD ? B : A;
+            Frag (&rgb0_out)[HN] = FOLD ? A : B;
+            if constexpr (ENCMAJOR) linear_encmajor<RG, ACT, RT, WT, false>(ring, rgb0_bias, h, rgb0_in, rgb0_out, enc, sigw, st);
+            else linear<PREC, RG, ACT, BIGENC, RT, WT, false, false, TRAIN, S_WT>(ring, rgb0_bias, h, rgb0_in, rgb0_out, true, enc, sigw, st, nullptr, 0, zt, a.tape_z_tile[li], a.tape_ed_tile);
             ++li;
             // ---- rgb.2 + widened sigmoid (model.py:54, activations.py:18-20) ----------------
             f32x16 out;
-            linear<PREC, RG, -1, BIGENC, 1, RT, false>(ring, cst + li * BIAS_STRIDE, h, B, A, false, enc, sigw, st, &out);
+            linear<PREC, RG, -1, BIGENC, 1, RT, false>(ring, cst + li * BIAS_STRIDE, h, rgb0_out, rgb0_in, false, enc, sigw, st, &out);
             if (valid && h == 0) {
                 // rows 0..2 of the output tile sit in accumulator registers 0..2 of lane half 0
 #pragma unroll

@@ -35,16 +35,18 @@ struct WTask {
     int out_dim, enc_kind, enc_n, enc_cols, ld, chain_dim;
 };
 
-struct GradList { float* p[2 + 2 * MAX_LAYERS + 8]; };
+struct GradList { float* p[2 + 2 * MAX_LAYERS + 8 + 2]; };   // the caller's tensors, then the folded rgb.0's weight and bias
 
 static void build_tasks(const ModelPlan& p, std::vector<WTask>& out) {
     struct A { int tile, kind, row0; };
     struct B { int tile, kind, map, col0; };
     const int spu = slots_per_unit(p.prec);
     const int hd = p.hd, n_jobs = p.n_layers + 1;                   // every Linear + the density head
+    const int n_tensors = 2 + 4 * hd + 8;
     for (int job = 0; job < n_jobs; ++job) {
         const bool sigma = job == p.n_layers;
-        const LayerPlan& L = p.layer[sigma ? 2 * hd : job];          // density head: same input as `features`
+        if (!sigma && p.layer[job].absent) continue;                 // `features`: its gradient comes out of rgb.0's (unfold_kernel)
+        const LayerPlan& L = p.layer[sigma ? 2 * hd : job];          // density head: a width-wide input, like `features`' plan
         std::vector<A> outs;
         std::vector<B> ins;
         int w_index, out_dim;
@@ -53,6 +55,7 @@ static void build_tasks(const ModelPlan& p, std::vector<WTask>& out) {
             w_index = 2 + 4 * hd; out_dim = 1;
         } else {
             w_index = job < 2 * hd ? 2 + 2 * job : 2 + 4 * hd + 2 + 2 * (job - 2 * hd);
+            if (L.folded) w_index = n_tensors;                       // the folded layer's own gradient (GradList)
             out_dim = L.out_dim;
             if (job == p.n_layers - 1) outs.push_back({p.tape_heads_tile, WO_RGB, 0});
             else
@@ -64,7 +67,7 @@ static void build_tasks(const ModelPlan& p, std::vector<WTask>& out) {
             for (int t = 0; t < L.enc_units * spu / 32; ++t) ins.push_back({base + t, WB_RAW, WM_ENC, 32 * t});
         }
         if (L.chain_tiles) {
-            const int src = sigma ? 2 * hd - 1 : job - 1;            // the layer whose output feeds this one
+            const int src = sigma || L.folded ? 2 * hd - 1 : job - 1;   // the layer whose output feeds this one
             const int kind = src == 2 * hd ? WB_RAW : WB_ACT;        // `features` has no activation
             for (int t = 0; t < L.chain_tiles; ++t)
                 if (L.chain_dim > 32 * t) ins.push_back({p.tape_z_tile[src] + t, kind, WM_CHAIN, 32 * t});
@@ -343,6 +346,60 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WTask* __restri
     else dst[(size_t)row * tk.ld + col] = sum;
 }
 
+// The gradients of `features` and rgb.0 from the gradient of the folded layer (LayerPlan::folded):
+// with W' = [W_r's encoder columns | W_rc W_f], b' = b_r + W_rc b_f (W_rc = W_r's chained columns),
+//     dW_rc = dW'_c W_f^T + db' b_f^T,   dW_r's encoder columns = dW'_e,   db_r = db',
+//     dW_f  = W_rc^T dW'_c,              db_f = W_rc^T db',
+// with the weights as they were when the streams of this step's forward were packed (fold_dev).
+// Workgroup (row, column group, part): part 0 = row r of rgb.0's gradient, part 1 = row k of `features`'
+// (column `width` = its bias); a row is a vector (in LDS) times a matrix whose rows are read coalesced;
+// four quarters of the sum in double, in index order, added in a fixed order.
+__global__ __launch_bounds__(256) void unfold_kernel(nerfx_model::FoldSpots f, int half, int width, int ed_cols,
+                                                     float* __restrict__ g_wr, float* __restrict__ g_br,
+                                                     float* __restrict__ g_wf, float* __restrict__ g_bf,
+                                                     float* __restrict__ found_inf) {
+    __shared__ float s_vec[256];
+    __shared__ double s_part[4][64];
+    const int ld = ed_cols + width, part = blockIdx.z, row = blockIdx.x;
+    const int n = part == 0 ? width : half;                          // length of the sums
+    if (row >= (part == 0 ? half : width)) return;
+    if (part == 0) {
+        for (int j = threadIdx.x; j < n; j += 256) s_vec[j] = f.gw[(int64_t)row * ld + ed_cols + j];
+        if (blockIdx.y == 0) {
+            if (g_wr) for (int c = threadIdx.x; c < ed_cols; c += 256) g_wr[(int64_t)row * ld + c] = f.gw[(int64_t)row * ld + c];
+            if (g_br && threadIdx.x == 0) g_br[row] = f.gb[row];
+        }
+    } else {
+        for (int r = threadIdx.x; r < n; r += 256) s_vec[r] = f.wr[(int64_t)r * width + row];
+    }
+    __syncthreads();
+    const int j = threadIdx.x & 63, quarter = threadIdx.x >> 6, c = 64 * blockIdx.y + j;
+    const int q0 = quarter * (n / 4), q1 = q0 + n / 4;               // (width and half are multiples of 8)
+    const int cols = part == 0 ? width : width + 1;
+    double s = 0.0;
+    if (c < cols) {
+        if (part == 0) {                                             // . column c of W_f^T
+#pragma unroll 8
+            for (int i = q0; i < q1; ++i) s = fma((double)s_vec[i], (double)f.wft[(int64_t)i * width + c], s);
+        } else if (c < width) {                                      // . column c of dW'_c
+#pragma unroll 8
+            for (int i = q0; i < q1; ++i) s = fma((double)s_vec[i], (double)f.gw[(int64_t)i * ld + ed_cols + c], s);
+        } else {                                                     // . db'
+            for (int i = q0; i < q1; ++i) s = fma((double)s_vec[i], (double)f.gb[i], s);
+        }
+    }
+    s_part[quarter][j] = s;
+    __syncthreads();
+    if (quarter != 0 || c >= cols) return;
+    double total = ((s_part[0][j] + s_part[1][j]) + s_part[2][j]) + s_part[3][j];
+    if (part == 0) total = fma((double)f.gb[row], (double)f.bf[c], total);
+    const float v = (float)total;
+    if (found_inf && !(fabsf(v) <= 3.402823466e38f)) *found_inf = 1.0f;
+    if (part == 0) { if (g_wr) g_wr[(int64_t)row * ld + ed_cols + c] = v; }
+    else if (c < width) { if (g_wf) g_wf[(int64_t)row * width + c] = v; }
+    else if (g_bf) g_bf[row] = v;
+}
+
 // Sample splits for a launch: as many as fit in WGRAD_ROUNDS full rounds of resident workgroups
 // (two per CU), never one more -- a few workgroups left over would run a round of their own.
 #ifndef WGRAD_ROUNDS
@@ -409,6 +466,13 @@ static int launch_wgrad_prec(const nerfx_model* m, uint64_t m_pad, const void* z
 #undef NERFX_WGRAD
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(n_tasks * (TASK_TILES * 1024 / 256)), dim3(256), 0, stream, tasks,
                        n_tasks, n_split, partial, grads, found_inf);
+    if (folds_features(PREC)) {
+        const ModelPlan& p = m->plan[PREC];
+        const LayerPlan& R = p.layer[2 * p.hd + 1];
+        const int half = R.out_dim, width = R.chain_dim, base = 2 + 4 * p.hd + 2;      // `features` weight, bias, rgb.0 weight, bias
+        hipLaunchKernelGGL(unfold_kernel, dim3(std::max(half, width), (width + 1 + 63) / 64, 2), dim3(256), 0, stream, m->fold_spots(),
+                           half, width, R.enc_cols, grads.p[base + 2], grads.p[base + 3], grads.p[base], grads.p[base + 1], found_inf);
+    }
     return launch_status("wgrad kernels");
 }
 
@@ -416,6 +480,9 @@ int launch_wgrad(const nerfx_model* m, int prec, uint64_t m_pad, const void* zta
                  float* const* grads, int n_grads, float* found_inf, hipStream_t stream) {
     GradList g{};
     for (int i = 0; i < n_grads; ++i) g.p[i] = grads[i];
+    const nerfx_model::FoldSpots f = m->fold_spots();
+    g.p[n_grads] = f.gw;
+    g.p[n_grads + 1] = f.gb;
     return prec == NERFX_PREC_BF16 ? launch_wgrad_prec<NERFX_PREC_BF16>(m, m_pad, ztape, gtape, partial, g, found_inf, stream)
                                    : launch_wgrad_prec<NERFX_PREC_FP32>(m, m_pad, ztape, gtape, partial, g, found_inf, stream);
 }

@@ -47,8 +47,8 @@ int make_plan(const nerfx_model_desc_t& d, int layout, ModelPlan& p) {
             L.n_tiles = 1; L.out_dim = 3; L.chain_tiles = p.rt; L.chain_dim = d.width / 2;
         }
         L.in_dim = L.enc_cols + L.chain_dim;
-        L.absent = layout == NERFX_LAYOUT_M16 && li == 2 * p.hd;    // `features`: folded into rgb.0 (see LayerPlan)
-        L.folded = layout == NERFX_LAYOUT_M16 && li == 2 * p.hd + 1;
+        L.absent = folds_features(layout) && li == 2 * p.hd;        // `features`: folded into rgb.0 (see LayerPlan)
+        L.folded = folds_features(layout) && li == 2 * p.hd + 1;
         L.group = group_tiles(prec, L.n_tiles);
         L.enc_major = layout == NERFX_STREAM_ENCMAJOR && L.enc_units > 0;
         L.enc_seg = L.enc_units / enc_block(prec) * pad_to_piece(enc_block(prec) * L.group);   // block-wise padding
@@ -65,16 +65,18 @@ int make_plan(const nerfx_model_desc_t& d, int layout, ModelPlan& p) {
         p.total_units += M16_STATIC_PAD;                            // never read by an MFMA, only carried through the ring
     }
     // backward chain
-    p.n_bwd = 2 * p.hd + 2;
+    const bool fold = folds_features(layout);
+    p.n_bwd = 2 * p.hd + (fold ? 1 : 2);
     unit = 0;
     for (int j = 0; j < p.n_bwd; ++j) {
-        const int src = 2 * p.hd + 2 - j;                           // rgb.2, rgb.0, features, trunk last .. 1
+        const int src = !fold || j < 2 ? 2 * p.hd + 2 - j : 2 * p.hd + 1 - j;   // rgb.2, rgb.0, features unless folded, trunk last .. 1
         const LayerPlan& F = p.layer[src];
         LayerPlan& L = p.bwd[j];
         L = LayerPlan{};
         L.n_tiles = F.chain_tiles; L.out_dim = F.chain_dim;
         L.chain_tiles = F.n_tiles; L.chain_dim = F.out_dim;
         L.transposed = 1; L.src_layer = src; L.src_ld = F.in_dim; L.src_col0 = F.enc_cols;
+        L.folded = F.folded;
         L.group = group_tiles(prec, L.n_tiles);
         L.chain_seg = pad_to_piece(L.chain_tiles * units_per_tile(prec) * L.group);
         L.unit0 = unit;
@@ -85,7 +87,7 @@ int make_plan(const nerfx_model_desc_t& d, int layout, ModelPlan& p) {
     int tile = 0;
     p.tape_ex_tile = tile; tile += ex_units * slots_per_unit(prec) / 32;
     p.tape_ed_tile = tile; tile += ed_units * slots_per_unit(prec) / 32;
-    for (int li = 0; li < p.n_layers - 1; ++li) { p.tape_z_tile[li] = tile; tile += p.layer[li].n_tiles; }
+    for (int li = 0; li < p.n_layers - 1; ++li) { p.tape_z_tile[li] = tile; tile += p.layer[li].absent ? 0 : p.layer[li].n_tiles; }
     p.tape_heads_tile = p.tape_z_tile[p.n_layers - 1] = tile; tile += 1;
     p.tape_tiles = tile;
     p.sigw_off = p.n_layers * BIAS_STRIDE;
@@ -238,14 +240,22 @@ __global__ __launch_bounds__(256) void pack_model_kernel(const PackLaunch a) {
 // quarters are added in a fixed order: the result does not depend on the launch.
 __global__ __launch_bounds__(256) void fold_colour_head_kernel(const float* __restrict__ Wr, const float* __restrict__ br,
                                                                const float* __restrict__ Wf, const float* __restrict__ bf,
-                                                               int width, int ed_cols, float* __restrict__ F, float* __restrict__ fb) {
+                                                               int width, int ed_cols, nerfx_model::FoldSpots out) {
     __shared__ float s_wr[256];
     __shared__ double s_part[4][64];
     const int r = blockIdx.x, ld = ed_cols + width;
     const float* wr = Wr + (int64_t)r * ld + ed_cols;
     for (int k = threadIdx.x; k < width; k += 256) s_wr[k] = wr[k];
-    if (blockIdx.y == 0)
-        for (int c = threadIdx.x; c < ed_cols; c += 256) F[(int64_t)r * ld + c] = Wr[(int64_t)r * ld + c];
+    if (blockIdx.y == 0) {
+        for (int c = threadIdx.x; c < ed_cols; c += 256) out.w[(int64_t)r * ld + c] = Wr[(int64_t)r * ld + c];
+        // the copies the gradients are unfolded with: this row of W_r's chained columns, and rows r,
+        // r + gridDim.x, .. of W_f (stored transposed) and b_f
+        for (int k = threadIdx.x; k < width; k += 256) out.wr[(int64_t)r * width + k] = wr[k];
+        for (int row = r; row < width; row += gridDim.x) {
+            for (int k = threadIdx.x; k < width; k += 256) out.wft[(int64_t)k * width + row] = Wf[(int64_t)row * width + k];
+            if (threadIdx.x == 0) out.bf[row] = bf[row];
+        }
+    }
     __syncthreads();
     const int j = threadIdx.x & 63, quarter = threadIdx.x >> 6, c = 64 * blockIdx.y + j;
     const int k0 = quarter * (width / 4), k1 = k0 + width / 4;      // (width is a multiple of 16)
@@ -260,8 +270,8 @@ __global__ __launch_bounds__(256) void fold_colour_head_kernel(const float* __re
     __syncthreads();
     if (quarter == 0 && c <= width) {
         const double total = ((s_part[0][j] + s_part[1][j]) + s_part[2][j]) + s_part[3][j];
-        if (c < width) F[(int64_t)r * ld + ed_cols + c] = (float)total;
-        else fb[r] = (float)((double)br[r] + total);
+        if (c < width) out.w[(int64_t)r * ld + ed_cols + c] = (float)total;
+        else out.b[r] = (float)((double)br[r] + total);
     }
 }
 
@@ -304,14 +314,15 @@ static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipSt
     PackLaunch a{};
     for (int i = 0; i < m->n_tensors; ++i) a.tensors[i] = tensors[i];
     const int fold_w = m->n_tensors, fold_b = m->n_tensors + 1;
-    if (m->has_m16) {
+    {
         const LayerPlan& R = p0.layer[2 * p0.hd + 1];
-        float* fb = m->fold_dev + (size_t)R.out_dim * R.in_dim;
-        hipLaunchKernelGGL(fold_colour_head_kernel, dim3(R.out_dim, (d.width + 1 + 63) / 64), dim3(256), 0, stream, tensors[tensor_index(p0, 2 * p0.hd + 1, false)],
-                           tensors[tensor_index(p0, 2 * p0.hd + 1, true)], tensors[tensor_index(p0, 2 * p0.hd, false)],
-                           tensors[tensor_index(p0, 2 * p0.hd, true)], d.width, R.enc_cols, m->fold_dev, fb);
-        a.tensors[fold_w] = m->fold_dev;
-        a.tensors[fold_b] = fb;
+        const nerfx_model::FoldSpots f = m->fold_spots();
+        hipLaunchKernelGGL(fold_colour_head_kernel, dim3(R.out_dim, (d.width + 1 + 63) / 64), dim3(256), 0, stream,
+                           tensors[tensor_index(p0, 2 * p0.hd + 1, false)], tensors[tensor_index(p0, 2 * p0.hd + 1, true)],
+                           tensors[tensor_index(p0, 2 * p0.hd, false)], tensors[tensor_index(p0, 2 * p0.hd, true)], d.width,
+                           R.enc_cols, f);
+        a.tensors[fold_w] = f.w;
+        a.tensors[fold_b] = f.b;
     }
     auto nan_class = [&](int li) { return (uint8_t)(li < 2 * p0.hd ? NAN_SIGMA | NAN_RGB : NAN_RGB); };
     auto add_stream = [&](int layout, bool with_bwd) {
@@ -322,9 +333,9 @@ static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipSt
         a.n_fwd[layout] = p.n_layers;
         for (int li = 0; li < p.n_layers + (with_bwd ? p.n_bwd : 0); ++li) {
             const bool fwd = li < p.n_layers;
-            const int src_layer = fwd ? li : p.bwd[li - p.n_layers].src_layer;
-            if (fwd && p.layer[li].absent) continue;
-            const int tensor = fwd && p.layer[li].folded ? fold_w : tensor_index(p, src_layer, false);
+            const LayerPlan& L = fwd ? p.layer[li] : p.bwd[li - p.n_layers];
+            if (L.absent) continue;
+            const int tensor = L.folded ? fold_w : tensor_index(p, fwd ? li : L.src_layer, false);
             a.job[a.n_jobs++] = PackJob{(uint8_t)layout, (uint8_t)li, (uint8_t)tensor, fwd ? nan_class(li) : (uint8_t)0};
         }
     };
@@ -337,11 +348,11 @@ static int pack_all(nerfx_model* m, const float* const* tensors, int mask, hipSt
         const int v = a.n_vec++;
         a.vec_tensor[v] = (uint8_t)tensor; a.vec_class[v] = (uint8_t)cls; a.vec_n[v] = n; a.vec_cap[v] = cap; a.vec_off[v] = off;
     };
-    for (int li = 0; li < p0.n_layers; ++li)
+    for (int li = 0; li < p0.n_layers; ++li)                           // (the rows of `features` and rgb.0 are read by no kernel)
         vec(tensor_index(p0, li, true), p0.layer[li].out_dim, BIAS_STRIDE, li * BIAS_STRIDE, nan_class(li));
     vec(2 + 4 * p0.hd, d.width, BIAS_STRIDE, p0.sigw_off, NAN_SIGMA);
     vec(2 + 4 * p0.hd + 1, 1, 4, p0.sigb_off, NAN_SIGMA);
-    if (m->has_m16) vec(fold_b, d.width / 2, BIAS_STRIDE / 2, p0.foldb_off, NAN_RGB);
+    vec(fold_b, d.width / 2, BIAS_STRIDE / 2, p0.foldb_off, NAN_RGB);
     a.consts = m->const_dev;
     m->pack_epoch += 1;                                                // see nerfx_model::nan_flags_dev
     a.nan_set = m->nan_flags_dev + (m->pack_epoch & 1);
@@ -392,10 +403,7 @@ extern "C" int nerfx_model_create(const nerfx_model_desc_t* desc, const float* c
         e = hipMalloc(&m->stream_bwd_dev[prec], (size_t)m->plan[prec].bwd_units * UNIT_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&m->const_dev, (size_t)m->plan[0].const_floats * sizeof(float));
     if (e == hipSuccess && m->narrow.ok) e = hipMalloc(&m->narrow_dev, (size_t)m->narrow.bytes);
-    if (e == hipSuccess && m->has_m16) {
-        const LayerPlan& R = m->plan[0].layer[desc->depth + 1];
-        e = hipMalloc((void**)&m->fold_dev, ((size_t)R.out_dim * R.in_dim + R.out_dim) * sizeof(float));
-    }
+    if (e == hipSuccess) e = hipMalloc((void**)&m->fold_dev, (size_t)m->fold_spots().floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&m->nan_flags_dev, 2 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(m->nan_flags_dev, 0, 2 * sizeof(uint32_t));
     if (e != hipSuccess) {
