@@ -62,9 +62,9 @@ def simulate(segs, R, defer, blocks=6, chunk=4, ahead=4):
                 refill(n, 0, first, k)
     return bad
 dens = [32] + [32]*4 + [40]*4 + [32]*4
-col = dens + [32]*4 + [40]*2 + [16]
+col = dens + [40]*2 + [32]                      # rgb.0 with `features` folded in, rgb.2 + 24 padding units
 dens4 = [32] + [32]*4*3 + [40]*4 + [32]*4*3
-col4 = dens4 + [32]*4 + [40]*2 + [8]
+col4 = dens4 + [40]*2 + [8]
 for name, segs in (("dens", dens), ("col", col), ("dens4", dens4), ("col4", col4)):
     for R in (80, 112):
         for defer in (False, True):
