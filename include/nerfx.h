@@ -383,6 +383,18 @@ void nerfx_debug_set_k4_fast(int enable);
  * default on. */
 void nerfx_debug_set_narrow(int enable);
 
+/* No counterpart in the reference.  The bf16 kernels evaluate rgb.0(phi_d, features(h)) (model.py:51-53,
+ * :76) as one layer on [phi_d | h]: weight [W_r's encoder columns | W_rc W_f], bias b_r + W_rc b_f (W_rc =
+ * the chained columns of rgb.0.weight), formed in fp32 at every refresh.  nerfx_debug_folded_head copies
+ * that weight (width/2 x (E_d + width), row-major) and bias (width/2) out; nerfx_debug_unfold_grads runs
+ * the step that turns the folded layer's gradient (g_w, g_b, same shapes) into the gradients of
+ * rgb.0.weight / .bias and features.weight / .bias with the model's current copies of the weights
+ * (any output may be NULL).  For tests that hold both against torch. */
+int nerfx_debug_folded_head(const nerfx_model_t* model, float* weight, float* bias, void* stream);
+int nerfx_debug_unfold_grads(const nerfx_model_t* model, const float* g_w, const float* g_b,
+                             float* g_rgb0_weight, float* g_rgb0_bias, float* g_features_weight,
+                             float* g_features_bias, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,8 @@ SIGNATURES = {
     "nerfx_debug_set_m16": (None, [_i]),
     "nerfx_debug_set_k4_fast": (None, [_i]),
     "nerfx_debug_set_narrow": (None, [_i]),
+    "nerfx_debug_folded_head": (_i, [_p, _p, _p, _p]),
+    "nerfx_debug_unfold_grads": (_i, [_p, _p, _p, _p, _p, _p, _p, _p]),
     "nerfx_render_workspace_bytes": (_l, [_l, _i, _i]),
     "nerfx_render_fwd": (_i, [_p, _p, _i, _p, _p, _l, _f, _f, _i, _i, _p, _p, _p, _l,
                               _p, _p, _p, _p, _p]),

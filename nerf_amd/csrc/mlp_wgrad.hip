@@ -441,6 +441,15 @@ int64_t wgrad_partial_bytes(const nerfx_model* m, int prec, uint64_t m_pad) {
     return (int64_t)n_split * m->n_wtasks[prec] * (TASK_TILES * 1024) * (int64_t)sizeof(float);
 }
 
+static void launch_unfold(const nerfx_model* m, float* g_wr, float* g_br, float* g_wf, float* g_bf, float* found_inf,
+                          hipStream_t stream) {
+    const ModelPlan& p = m->plan[0];
+    const LayerPlan& R = p.layer[2 * p.hd + 1];
+    const int half = R.out_dim, width = R.chain_dim;
+    hipLaunchKernelGGL(unfold_kernel, dim3(std::max(half, width), (width + 1 + 63) / 64, 2), dim3(256), 0, stream, m->fold_spots(),
+                       half, width, R.enc_cols, g_wr, g_br, g_wf, g_bf, found_inf);
+}
+
 template <int PREC>
 static int launch_wgrad_prec(const nerfx_model* m, uint64_t m_pad, const void* ztape, const void* gtape, float* partial,
                              const GradList& grads, float* found_inf, hipStream_t stream) {
@@ -467,11 +476,8 @@ static int launch_wgrad_prec(const nerfx_model* m, uint64_t m_pad, const void* z
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(n_tasks * (TASK_TILES * 1024 / 256)), dim3(256), 0, stream, tasks,
                        n_tasks, n_split, partial, grads, found_inf);
     if (folds_features(PREC)) {
-        const ModelPlan& p = m->plan[PREC];
-        const LayerPlan& R = p.layer[2 * p.hd + 1];
-        const int half = R.out_dim, width = R.chain_dim, base = 2 + 4 * p.hd + 2;      // `features` weight, bias, rgb.0 weight, bias
-        hipLaunchKernelGGL(unfold_kernel, dim3(std::max(half, width), (width + 1 + 63) / 64, 2), dim3(256), 0, stream, m->fold_spots(),
-                           half, width, R.enc_cols, grads.p[base + 2], grads.p[base + 3], grads.p[base], grads.p[base + 1], found_inf);
+        const int base = 2 + 4 * m->plan[PREC].hd + 2;               // `features` weight, bias, rgb.0 weight, bias
+        launch_unfold(m, grads.p[base + 2], grads.p[base + 3], grads.p[base], grads.p[base + 1], found_inf, stream);
     }
     return launch_status("wgrad kernels");
 }
@@ -488,3 +494,25 @@ int launch_wgrad(const nerfx_model* m, int prec, uint64_t m_pad, const void* zta
 }
 
 }  // namespace nerfx
+
+using namespace nerfx;
+
+extern "C" int nerfx_debug_folded_head(const nerfx_model_t* model, float* weight, float* bias, void* stream) {
+    NERFX_REQUIRE(model && weight && bias, "NULL argument");
+    const LayerPlan& R = model->plan[0].layer[2 * model->plan[0].hd + 1];
+    const nerfx_model::FoldSpots f = model->fold_spots();
+    NERFX_HIP(hipMemcpyAsync(weight, f.w, (size_t)R.out_dim * R.in_dim * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    NERFX_HIP(hipMemcpyAsync(bias, f.b, (size_t)R.out_dim * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int nerfx_debug_unfold_grads(const nerfx_model_t* model, const float* g_w, const float* g_b, float* g_rgb0_weight,
+                                        float* g_rgb0_bias, float* g_features_weight, float* g_features_bias, void* stream) {
+    NERFX_REQUIRE(model && g_w && g_b, "NULL argument");
+    const LayerPlan& R = model->plan[0].layer[2 * model->plan[0].hd + 1];
+    const nerfx_model::FoldSpots f = model->fold_spots();
+    NERFX_HIP(hipMemcpyAsync(f.gw, g_w, (size_t)R.out_dim * R.in_dim * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    NERFX_HIP(hipMemcpyAsync(f.gb, g_b, (size_t)R.out_dim * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    launch_unfold(model, g_rgb0_weight, g_rgb0_bias, g_features_weight, g_features_bias, nullptr, (hipStream_t)stream);
+    return launch_status("unfold_kernel");
+}

@@ -217,3 +217,52 @@ def test_fused_grad_scaler_step_matches_torch_grad_scaler(ops):
     for k, (a, b) in enumerate(zip(w_a, w_b)):
         assert bool(torch.isfinite(a).all())
         assert_close(a, b, rtol=1e-4, atol=2e-6, what=f"weights after 5 steps (one skipped), tensor {k}")
+
+
+@pytest.mark.parametrize("shape", ["256x4", "192x4 Fourier d", "32x2"])
+def test_folded_colour_head_and_its_unfolded_gradients(ops, shape):
+    """The bf16 kernels evaluate rgb.0(phi_d, features(h)) as one layer (model.py:51-53, :76).  Its weight
+    and bias, as the library forms them at a refresh, equal [W_r's encoder columns | W_rc W_f] and
+    b_r + W_rc b_f in float64 to fp32 rounding; and the step that turns that layer's gradient into the
+    gradients of the two original layers equals autograd through the fold in float64."""
+    import ctypes as C
+    from nerf_amd import _lib
+    from nerf_amd.core import FourierFeatures, NeRF, PositionalEncoding
+    torch.manual_seed(5)
+    if shape == "256x4":
+        model = NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 6), 256, 4)
+    elif shape == "192x4 Fourier d":
+        model = NeRF(PositionalEncoding(3, 6), FourierFeatures(3, 24, 4.0), 192, 4)
+    else:
+        model = NeRF(PositionalEncoding(3, 6), PositionalEncoding(3, 6), 32, 2, resid=False)
+    model = model.cuda()
+    with torch.no_grad():                                         # biases that matter
+        model.features.bias.normal_()
+        dict(model.named_parameters())["rgb.0.bias"].normal_()
+    handle = ops.handle_for(model)
+    ptr = handle.ready(_lib.PREC_BF16)
+    sd = {k: v.detach().double().cpu() for k, v in model.named_parameters()}
+    W_r, b_r, W_f, b_f = sd["rgb.0.weight"], sd["rgb.0.bias"], sd["features.weight"], sd["features.bias"]
+    half, ld = W_r.shape
+    width = W_f.shape[0]
+    E = ld - width
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    w, b = torch.empty(half, ld, device="cuda"), torch.empty(half, device="cuda")
+    _lib.check(_lib.lib.nerfx_debug_folded_head(ptr, p(w), p(b), stream))
+    want_w = torch.cat([W_r[:, :E], W_r[:, E:] @ W_f], dim=1)
+    want_b = b_r + W_r[:, E:] @ b_f
+    assert_close(w.cpu().double(), want_w, 0.0, 2e-7 * float(want_w.abs().max()), "folded weight")
+    assert_close(b.cpu().double(), want_b, 0.0, 2e-7 * float(want_b.abs().max()), "folded bias")
+    # gradients: any dL/dW', dL/db' -> the four gradients, against autograd through the fold
+    g_w, g_b = torch.randn(half, ld, dtype=torch.float64), torch.randn(half, dtype=torch.float64)
+    leaves = [t.clone().requires_grad_(True) for t in (W_r, b_r, W_f, b_f)]
+    folded_w = torch.cat([leaves[0][:, :E], leaves[0][:, E:] @ leaves[2]], dim=1)
+    folded_b = leaves[1] + leaves[0][:, E:] @ leaves[3]
+    ((folded_w * g_w).sum() + (folded_b * g_b).sum()).backward()
+    outs = [torch.empty_like(t, dtype=torch.float32, device="cuda") for t in (W_r, b_r, W_f, b_f)]
+    gw32, gb32 = g_w.float().cuda(), g_b.float().cuda()
+    _lib.check(_lib.lib.nerfx_debug_unfold_grads(ptr, p(gw32), p(gb32), p(outs[0]), p(outs[1]), p(outs[2]), p(outs[3]), stream))
+    torch.cuda.synchronize()
+    for name, got, leaf in zip(("rgb.0.weight", "rgb.0.bias", "features.weight", "features.bias"), outs, leaves):
+        assert_close(got.cpu().double(), leaf.grad, 0.0, 3e-6 * float(leaf.grad.abs().max()), f"unfolded gradient of {name}")
